@@ -1,0 +1,80 @@
+"""Synthetic Big-Vul-shaped samples: there is no dataset, Joern or
+image renderer on the box, so every benchmark / test input is generated here,
+deterministically from the sample index (rank-independent).
+
+Per function:
+  image   [3,S,S] ~ U(-1.7,1.7) (unit variance, post-Normalize statistics)
+  ids     [512] int64: ``<s> <encoder-only> </s>`` (0, 6, 2) then tokens uniform
+          in [5, vocab), ``</s>``, then pad id 1; valid length ~ U[128, 512]
+  graph   N ~ U{lo..hi} line-level nodes; directed edges = (N-1) random-tree "AST"
+          + N "CFG" chain/branch + N random "CDG" (duplicates allowed) + N self-loops
+          => E = 4N-1; ``_UNIX_NODE_EMB`` [N,768] ~ 0.5*U(-1.7,1.7), ``pos_emb`` [N,4]
+          ~ U(0,1) with ~10 % rows zeroed (OCR misses), ``_FUNC_EMB`` filled by the caller
+  label   Bernoulli(0.5)
+
+Mirrors the schema ImageList.item / __getitem__ produce in the reference
+(mvuld/data/data_list.py:107-141,265-317).
+"""
+import numpy as np
+import torch
+
+from .. import synth
+from ..graph import BatchedGraph, batch as batch_graphs
+
+
+def make_graph(index: int, n_lo=150, n_hi=250, emb=768, salt=0) -> BatchedGraph:
+    tag = f"graph/{index}"
+    n = int(synth.ints(tag + "/n", (1,), n_lo, n_hi + 1, salt)[0])
+    # AST: node i>0 hangs under a random earlier node
+    par = (synth.unit(tag + "/ast", n - 1, salt).astype(np.float64) * 0.5 + 0.5)
+    ast_src = np.minimum((par * np.arange(1, n)).astype(np.int64), np.arange(1, n) - 1)
+    ast_dst = np.arange(1, n, dtype=np.int64)
+    # CFG: chain i -> i+1 with occasional forward/backward branch; last node loops to 0
+    br = synth.unit(tag + "/cfgb", n, salt)
+    tgt = synth.ints(tag + "/cfgt", (n,), 0, n, salt).numpy()
+    cfg_src = np.arange(n, dtype=np.int64)
+    cfg_dst = np.where(br > 0.7, tgt, (np.arange(n) + 1) % n).astype(np.int64)
+    # CDG: random pairs, duplicates allowed
+    cdg_src = synth.ints(tag + "/cdgs", (n,), 0, n, salt).numpy()
+    cdg_dst = synth.ints(tag + "/cdgd", (n,), 0, n, salt).numpy()
+    loops = np.arange(n, dtype=np.int64)
+    src = np.concatenate([ast_src, cfg_src, cdg_src, loops])
+    dst = np.concatenate([ast_dst, cfg_dst, cdg_dst, loops])
+    etype = np.concatenate([np.zeros(n - 1), np.ones(n), np.full(n, 2), np.zeros(n)]).astype(np.int64)
+    node = synth.tensor(tag + "/emb", (n, emb), -0.85, 0.85, salt)
+    pos = synth.tensor(tag + "/pos", (n, 4), 0.0, 1.0, salt)
+    miss = torch.from_numpy(synth.unit(tag + "/miss", n, salt) > 0.8)
+    pos[miss] = 0.0
+    g = BatchedGraph(torch.from_numpy(src), torch.from_numpy(dst), [n],
+                     {"_UNIX_NODE_EMB": node, "pos_emb": pos,
+                      "_lineno": torch.arange(1, n + 1, dtype=torch.int64)},
+                     {"_ETYPE": torch.from_numpy(etype)})
+    return g
+
+
+def make_ids(index: int, length=512, vocab=51416, pad=1, lo=128, salt=0) -> torch.Tensor:
+    tag = f"ids/{index}"
+    valid = int(synth.ints(tag + "/len", (1,), min(lo, length), length + 1, salt)[0])
+    ids = synth.ints(tag + "/tok", (length,), 5, vocab, salt)
+    ids[0], ids[1], ids[2] = 0, 6, 2
+    ids[valid - 1] = 2
+    ids[valid:] = pad
+    return ids
+
+
+def make_image(index: int, size=448, salt=0) -> torch.Tensor:
+    return synth.tensor(f"img/{index}", (3, size, size), -1.7, 1.7, salt)
+
+
+def make_label(index: int, salt=0) -> int:
+    return int(synth.unit(f"label/{index}", 1, salt)[0] > 0)
+
+
+def make_batch(indices, img_size=448, seq_len=512, vocab=51416, n_lo=150, n_hi=250, salt=0):
+    """(graph, images [B,3,S,S], ids [B,L], labels [B]) for the fused model."""
+    graphs = [make_graph(i, n_lo, n_hi, salt=salt) for i in indices]
+    g = batch_graphs(graphs)
+    images = torch.stack([make_image(i, img_size, salt) for i in indices])
+    ids = torch.stack([make_ids(i, seq_len, vocab, salt=salt) for i in indices])
+    labels = torch.tensor([make_label(i, salt) for i in indices], dtype=torch.int64)
+    return g, images, ids, labels

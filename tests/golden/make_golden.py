@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE modules next to the oracle.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing of
+the reference is copied: the reference's python files are imported where they
+lie and executed on synthetic weights/inputs that ``mvuld_amd.synth`` regenerates
+bit-identically anywhere; only output tensors are stored.
+
+What is pinned by the reference's own code:
+  * SwinV2 forward_features  <- mvuld/models/swin_transformer_v2.py, imported
+    unmodified under a 3-symbol stand-in for ``timm.models.layers``
+    (DropPath / to_2tuple / trunc_normal_: init + stochastic depth only).
+  * Rs_GCN                   <- mvuld/models/Rs_GCN.py, imported directly.
+  * Head forward text        <- mvuld/models/GraphModel.py
+    ``Multi_DefectModel_new_GCN.forward`` executed under stand-ins for torch._six,
+    torchvision.models (unused import), timm.models.layers and a minimal ``dgl``
+    whose ``GATConv`` is the documented DGL 0.8.1 algorithm (third party: the
+    GAT arithmetic itself stays "parity unpinned").
+What is pinned against an installed third-party library instead:
+  * RoBERTa encoder          <- installed transformers RobertaModel (5.x here;
+    the reference pins 4.18.0) with the 4-D additive mask equivalent to the
+    reference's 3-D mask (unixcoder.py:36) -- "parity unpinned" w.r.t. 4.18.0.
+
+Usage:  python tests/golden/make_golden.py [--out tests/golden]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/mvuld"
+
+from mvuld_amd import synth                      # noqa: E402
+from mvuld_amd.data import synthetic             # noqa: E402
+from oracle import swin_ref, roberta_ref, head_ref, fused_ref   # noqa: E402
+
+
+# --------------------------------------------------------------------------- stand-ins
+def install_standins():
+    timm = types.ModuleType("timm"); tm = types.ModuleType("timm.models"); tl = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__(); self.p = p
+
+        def forward(self, x):
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * m / keep
+
+    tl.DropPath = DropPath
+    tl.to_2tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    tl.trunc_normal_ = lambda t, std=1.0, **kw: nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+    timm.models = tm; tm.layers = tl
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl})
+    six = types.ModuleType("torch._six"); six.inf = float("inf"); sys.modules["torch._six"] = six
+    tv = types.ModuleType("torchvision"); tvm = types.ModuleType("torchvision.models"); tv.models = tvm
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm})
+
+    # ---- minimal dgl: graph object + GATConv (documented 0.8.1 algorithm) + unbatch
+    dgl = types.ModuleType("dgl"); dnn = types.ModuleType("dgl.nn"); dpt = types.ModuleType("dgl.nn.pytorch")
+
+    class G:
+        def __init__(self, src, dst, bnn, ndata):
+            self.src, self.dst, self.bnn, self.ndata = src, dst, list(bnn), dict(ndata)
+
+        def number_of_nodes(self):
+            return int(sum(self.bnn))
+
+    class GATConv(nn.Module):
+        def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2,
+                     residual=False, activation=None, allow_zero_in_degree=False, bias=True):
+            super().__init__()
+            self.H, self.O, self.slope = num_heads, out_feats, negative_slope
+            self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+            self.attn_l = nn.Parameter(torch.zeros(1, num_heads, out_feats))
+            self.attn_r = nn.Parameter(torch.zeros(1, num_heads, out_feats))
+            self.bias = nn.Parameter(torch.zeros(num_heads * out_feats))
+            self.feat_drop = nn.Dropout(feat_drop)
+
+        def forward(self, g, feat):
+            sd = {"fc.weight": self.fc.weight, "attn_l": self.attn_l, "attn_r": self.attn_r, "bias": self.bias}
+            return head_ref.gat_conv(sd, "", self.feat_drop(feat), g.src, g.dst, self.H, self.O, self.slope)
+
+    def unbatch(g):
+        out, o = [], 0
+        for n in g.bnn:
+            out.append(G(None, None, [n], {k: v[o:o + n] for k, v in g.ndata.items()})); o += n
+        return out
+
+    dgl.unbatch = unbatch; dgl.G = G
+    dpt.GATConv = GATConv; dpt.GraphConv = nn.Identity; dpt.GatedGraphConv = nn.Identity
+    dgl.nn = dnn; dnn.pytorch = dpt
+    sys.modules.update({"dgl": dgl, "dgl.nn": dnn, "dgl.nn.pytorch": dpt})
+    return dgl
+
+
+def load_file(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_synth(module: nn.Module, prefix="", salt=0):
+    """Overwrite every parameter and BN buffer with its synthetic value (geometry buffers stay)."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith(("relative_coords_table", "relative_position_index", "attn_mask", "position_ids")):
+            continue
+        new[k] = synth.synth_param(prefix + k, tuple(v.shape), salt).to(v.dtype)
+    module.load_state_dict(new, strict=False)
+    return {prefix + k: v.clone() for k, v in new.items()}
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# --------------------------------------------------------------------------- cases
+SWIN_CASES = {
+    # name: (cfg kwargs, batch)
+    "swin_mini224": (dict(img_size=224, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=14), 2),
+    "swin_small448": (dict(img_size=448, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=28), 1),
+    "swin_base448": (dict(), 1),
+}
+
+
+def gen_swin(out, which):
+    ref = load_file("ref_swin_v2", f"{REF}/models/swin_transformer_v2.py")
+    for name, (kw, B) in SWIN_CASES.items():
+        if which and name not in which:
+            continue
+        cfg = swin_ref.SwinCfg(**kw)
+        m = ref.SwinTransformerV2(img_size=cfg.img_size, patch_size=4, in_chans=3, num_classes=2,
+                                  embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads,
+                                  window_size=cfg.window_size, drop_path_rate=0.2,
+                                  pretrained_window_sizes=cfg.pretrained_window_sizes).eval()
+        sd = load_synth(m)
+        shapes = swin_ref.swin_param_shapes(cfg)
+        assert set(shapes) == set(sd), (set(shapes) ^ set(sd))
+        x = torch.stack([synthetic.make_image(1000 + i, cfg.img_size) for i in range(B)])
+        with torch.no_grad():
+            y_ref = m.forward_features(x)
+            y_orc = swin_ref.swin_forward_features(sd, x, cfg)
+        e = rel_err(y_orc, y_ref)
+        print(f"[{name}] feat {tuple(y_ref.shape)} |ref|max={float(y_ref.abs().max()):.4f} oracle-vs-ref rel={e:.2e}")
+        assert e < 2e-5, e
+        np.savez(os.path.join(out, f"{name}.npz"), feat=y_ref.numpy(), image_index0=np.int64(1000), batch=np.int64(B))
+
+
+def gen_rsgcn(out):
+    ref = load_file("ref_rs_gcn", f"{REF}/models/Rs_GCN.py")
+    m = ref.Rs_GCN(512, 512)
+    sd = load_synth(m, "Rs_GCN_1.")
+    v = synth.tensor("rsgcn/in", (4, 512, 100), -1, 1)
+    res = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        # fresh running stats each mode
+        m.load_state_dict({k[len("Rs_GCN_1."):]: t for k, t in sd.items()}, strict=False)
+        with torch.no_grad():
+            y_ref, R_ref = m(v)
+            y_orc, R_orc = head_ref.rs_gcn(sd, "Rs_GCN_1.", v, mode == "train")
+        e = rel_err(y_orc, y_ref)
+        print(f"[rs_gcn/{mode}] rel={e:.2e} R rel={rel_err(R_orc, R_ref):.2e}")
+        assert e < 1e-5
+        res[f"y_{mode}"] = y_ref.numpy(); res[f"R_{mode}"] = R_ref.numpy()
+    np.savez(os.path.join(out, "rs_gcn.npz"), **res)
+
+
+HEAD_NODES = [60, 100, 130, 217]
+
+
+def head_inputs():
+    gs = [synthetic.make_graph(2000 + i, n, n) for i, n in enumerate(HEAD_NODES)]
+    from mvuld_amd.graph import batch
+    g = batch(gs)
+    img = synth.tensor("head/img", (len(gs), 1024), -1, 1)
+    txt = synth.tensor("head/txt", (len(gs), 768), -1, 1)
+    return g, img, txt
+
+
+def gen_head(out, dgl):
+    # GraphModel.py does ``from utils import ...`` and relative imports inside ``models``
+    sys.path.insert(0, REF)
+    import importlib
+    gm = importlib.import_module("models.GraphModel")
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    m = gm.Multi_DefectModel_new_GCN(cfg)
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    sd = load_synth(m)
+    shapes = head_ref.head_param_shapes(2)
+    assert set(shapes) == set(sd), (set(shapes) ^ set(sd))
+    g, img, txt = head_inputs()
+    res = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        m.load_state_dict(sd, strict=False)
+        rg = dgl.G(g.src, g.dst, g.batch_num_nodes().tolist(),
+                   {"_UNIX_NODE_EMB": g.ndata["_UNIX_NODE_EMB"], "pos_emb": g.ndata["pos_emb"],
+                    "_FUNC_EMB": txt.repeat_interleave(g.batch_num_nodes(), 0)})
+        with torch.no_grad():
+            y_ref = m(rg, img, txt)
+            y_orc = head_ref.head_forward(sd, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"],
+                                          g.ndata["pos_emb"], img, txt, training=(mode == "train"))
+        e = rel_err(y_orc, y_ref)
+        print(f"[head/{mode}] logits {y_ref.tolist()} rel={e:.2e}")
+        assert e < 2e-5
+        res[f"logits_{mode}"] = y_ref.numpy()
+    np.savez(os.path.join(out, "head.npz"), nodes=np.array(HEAD_NODES), **res)
+
+
+ROB_CASES = {
+    "roberta_tiny": (dict(vocab_size=1000, hidden_size=128, num_layers=2, num_heads=2, intermediate_size=512,
+                          max_position=130), 128, [128, 77, 5]),
+    "roberta_base512": (dict(), 512, [512, 301]),
+}
+
+
+def rob_ids(cfg, L, lens, tag):
+    rows = []
+    for i, n in enumerate(lens):
+        r = synth.ints(f"{tag}/{i}", (L,), 5, cfg.vocab_size)
+        r[0], r[1], r[2] = 0, 6, 2
+        r[n - 1] = 2
+        r[n:] = cfg.pad_token_id
+        rows.append(r)
+    return torch.stack(rows)
+
+
+def gen_roberta(out, which):
+    from transformers import RobertaConfig, RobertaModel
+    for name, (kw, L, lens) in ROB_CASES.items():
+        if which and name not in which:
+            continue
+        cfg = roberta_ref.RobertaCfg(**kw)
+        hc = RobertaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_layers,
+                           num_attention_heads=cfg.num_heads, intermediate_size=cfg.intermediate_size,
+                           max_position_embeddings=cfg.max_position, type_vocab_size=cfg.type_vocab_size,
+                           pad_token_id=cfg.pad_token_id, layer_norm_eps=cfg.ln_eps,
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        hc._attn_implementation = "eager"
+        m = RobertaModel(hc).eval()
+        sd = load_synth(m, "encoder.")
+        shapes = roberta_ref.roberta_param_shapes(cfg)
+        assert set(shapes) == set(sd), (set(shapes) ^ set(sd))
+        ids = rob_ids(cfg, L, lens, name)
+        mask = ids.ne(cfg.pad_token_id)
+        m3 = (mask[:, None, :] & mask[:, :, None]).float()
+        add = (1.0 - m3[:, None]) * -10000.0
+        with torch.no_grad():
+            tok_hf = m(ids, attention_mask=add)[0]
+            tok, sent = roberta_ref.unixcoder_sentence(sd, ids, cfg)
+        mf = mask.float()
+        sent_hf = (tok_hf * mf[..., None]).sum(1) / mf.sum(-1)[..., None]
+        e = rel_err(sent, sent_hf)
+        ev = float(((tok - tok_hf).abs() * mf[..., None]).max() / tok_hf.abs().max())
+        print(f"[{name}] sent rel={e:.2e} valid-token rel={ev:.2e}")
+        assert e < 2e-5 and ev < 2e-5
+        np.savez(os.path.join(out, f"{name}.npz"), sent=sent_hf.numpy(), lens=np.array(lens), L=np.int64(L))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    w = a.only
+    # transformers probes optional packages by name: run it before any stand-in is installed
+    if not w or any(s.startswith("roberta") for s in w):
+        gen_roberta(a.out, w)
+    dgl = install_standins()
+    if not w or any(s.startswith("swin") for s in w):
+        gen_swin(a.out, w)
+    if not w or "rs_gcn" in w:
+        gen_rsgcn(a.out)
+    if not w or "head" in w:
+        gen_head(a.out, dgl)
+
+
+if __name__ == "__main__":
+    main()
