@@ -1,0 +1,153 @@
+/* libmvuld_hip.so -- C ABI of the MI355X (gfx950) kernels behind MVulD's fused multimodal hot path.
+ *
+ * The reference (jacknichao/MVulD) has no native code and no FFI: every GPU kernel it runs comes
+ * from torch / cuDNN / DGL / transformers.  Each entry below therefore cites the reference *call
+ * site* (file:line under /root/reference/mvuld) whose implicit third-party kernel(s) it replaces.
+ *
+ * Conventions
+ *   - plain device pointers + explicit sizes; no torch types.  `dtype`: 0 = f32, 1 = bf16 storage
+ *     (math is always fp32; bf16 GEMMs accumulate in fp32 on the MFMA units).
+ *   - the caller owns every buffer, including workspaces and saved statistics.
+ *   - functions never allocate, never synchronise, never throw; they enqueue on `stream`
+ *     (pass torch.cuda.current_stream().cuda_stream) and return 0, or non-zero with a message
+ *     retrievable through mvuld_last_error() (thread-local).
+ *   - "atomic accumulate" outputs (parameter gradients) are fp32 and must be zeroed by the caller
+ *     once per optimisation step.
+ */
+#ifndef MVULD_HIP_H
+#define MVULD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mvuld_stream_t;
+
+enum { MVULD_F32 = 0, MVULD_BF16 = 1 };
+enum { MVULD_EPI_NONE = 0, MVULD_EPI_BIAS = 1, MVULD_EPI_GELU = 2, MVULD_EPI_ELU = 3, MVULD_EPI_MUL_DGELU = 4, MVULD_EPI_MUL_DELU = 5, MVULD_EPI_ADD_AUX = 6 };
+enum { MVULD_OUT_STORE = 0, MVULD_OUT_ACCUM = 1, MVULD_OUT_ATOMIC = 2 };
+
+int mvuld_version(void);
+const char* mvuld_last_error(void);
+
+/* C[b] = epilogue(alpha * A[b] . B[b]^T (+ bias[N]))   A [M,K] (lda), B [N,K] (ldb), C [M,N] (ldc), batch strides in elements.
+ * Replaces every nn.Linear / F.linear / Conv1d(k=1) / Conv2d(4x4,s4) / torch.matmul on the path:
+ *   swin_transformer_v2.py:150 (qkv), :177 (proj), :27-30 (Mlp), :361 (reduction), :490 (patch conv);
+ *   HF RobertaModel dense layers (unixcoder.py:36); GATConv.fc, GraphModel.py:153-209 Linear layers;
+ *   Rs_GCN.py:57-70 (g/theta/phi/W convs, theta^T.phi, R.g).
+ * epilogue GELU writes the pre-activation to `aux` (if non-null); MUL_DGELU / MUL_DELU multiply by the
+ * activation derivative taken from `aux` (pre-activation / ELU output); ADD_AUX adds `aux` (residual-gradient join).  out_mode ATOMIC (fp32 C only)
+ * with splitk > 1 is the weight-gradient form  dW += dY^T . X . */
+int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
+                  void* C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
+                  const float* bias, int epilogue, void* aux, int64_t ldaux, int64_t strideAux,
+                  float alpha, int out_mode, int splitk, int dtype_in, int dtype_out, int force_simple,
+                  mvuld_stream_t stream);
+
+/* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
+int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);
+
+/* out[c] += sum_r x[r*ld + c]  -- bias gradients (autograd of the `+ bias` in every Linear) */
+int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dtype, mvuld_stream_t stream);
+
+/* y = residual + rowscale[row / rows_per_sample] * (LayerNorm(x + pre) * gamma + beta).
+ * Swin res-post-norm + DropPath: swin_transformer_v2.py:301,304; plain LN :492,:362,:632; RoBERTa post-LN
+ * (LayerNorm(dense + input)) uses `pre` and keeps the sum in `xsum` for backward. */
+int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta,
+                        const void* residual, const float* rowscale, int rows_per_sample, void* y, float* mean,
+                        float* rstd, int64_t rows, int C, float eps, int dtype, mvuld_stream_t stream);
+/* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta atomic accumulate */
+int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                        const float* rowscale, int rows_per_sample, void* dx, float* dgamma, float* dbeta,
+                        int64_t rows, int C, int dtype, mvuld_stream_t stream);
+
+/* BatchNorm1d over a strided view: element (o,c,i) at o*so + c*sc + i*si, statistics over (o,i).
+ * GraphModel.py:153,158,186,187,208 (swinbn, bn_text, bn_gat, bn_bbox, final_fc_bn) and Rs_GCN.py:27-34 (W[1]). */
+int mvuld_batchnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* run_mean,
+                        float* run_var, float* save_mean, float* save_rstd, int O, int C, int I, int64_t so,
+                        int64_t sc, int64_t si, float eps, float momentum, int training, int dtype, mvuld_stream_t stream);
+int mvuld_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean,
+                        const float* save_rstd, void* dx, float* dgamma, float* dbeta, int O, int C, int I,
+                        int64_t so, int64_t sc, int64_t si, int training, int dtype, mvuld_stream_t stream);
+
+/* Fused attention (reference-quality VALU kernels; f32 | bf16 storage).
+ * mode 0: SwinV2 shifted-window cosine attention + continuous position bias + shift mask, with the roll /
+ *         window_partition / window_reverse of swin_transformer_v2.py:279-299 folded into the token index map
+ *         (WindowAttention.forward :140-179).  table16 = 16*sigmoid(cpb_mlp(coords)) [(2ws-1)^2, H].
+ * mode 1: pad-masked attention of the UniXcoder encoder (unixcoder.py:35-36; additive -10000 mask).
+ * qkv [tokens, 3*H*hd] rows = [3][H][hd]; out [tokens, H*hd]; lse [B*nW, H, N] fp32 saved for backward. */
+int mvuld_attn_fwd_simple(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
+                          const void* qkv, const float* table16, const float* logit_scale, const int* valid,
+                          void* out, float* lse, int dtype, mvuld_stream_t stream);
+int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
+                          const void* qkv, const float* table16, const float* logit_scale, const int* valid,
+                          const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
+                          float* dlogit_scale, int dtype, mvuld_stream_t stream);
+
+/* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
+int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,
+                        float* table16, int T2, int H, mvuld_stream_t stream);
+int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16,
+                        const float* dtable16, float* dW1, float* db1, float* dW2, int T2, int H, mvuld_stream_t stream);
+
+/* activation backward: mode 0 GELU(erf) with ref = pre-activation (Mlp, swin_transformer_v2.py:28; RoBERTa
+ * intermediate); mode 1 ELU with ref = output (F.elu, GraphModel.py:154-187) */
+int mvuld_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int mode, int dtype, mvuld_stream_t stream);
+int mvuld_elu_fwd(const void* x, void* y, int64_t n, int dtype, mvuld_stream_t stream);
+int mvuld_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t n, mvuld_stream_t stream);
+int mvuld_add(const void* a, const void* b, void* y, int64_t n, int dtype, mvuld_stream_t stream);
+/* y = x * keep / (1-p), keep = hash(seed, index) >= p: nn.Dropout of GraphModel.py:171-177, GATConv feat_drop,
+ * RoBERTa hidden dropout; the same call with the same seed is the backward */
+int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, mvuld_stream_t stream);
+
+/* PatchEmbed im2col (swin_transformer_v2.py:490) and PatchMerging's 2x2 gather-concat (:352-359) / its inverse */
+int mvuld_im2col_patch4(const float* img, void* cols, int B, int S, int dtype, mvuld_stream_t stream);
+int mvuld_patch_merge_gather(const void* src, void* dst, int B, int res, int C, int inverse, int dtype, mvuld_stream_t stream);
+
+/* RoBERTa embeddings (HF RobertaEmbeddings as called from unixcoder.py:36) */
+int mvuld_position_ids(const int64_t* ids, int* pos, int* valid, int B, int L, int pad, mvuld_stream_t stream);
+int mvuld_embed_fwd(const int64_t* ids, const int* pos, const float* word, const float* posw, const float* type0,
+                    void* out, int64_t ntok, int H, int vocab, int maxpos, int dtype, mvuld_stream_t stream);
+int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* dword, float* dposw, int64_t ntok, int H,
+                    int vocab, int maxpos, int dtype, mvuld_stream_t stream);
+
+/* (masked) mean over tokens: AdaptiveAvgPool1d (swin_transformer_v2.py:633) and the sentence vector (unixcoder.py:37) */
+int mvuld_mean_pool_fwd(const void* x, const int* valid, void* out, int B, int L, int C, int dtype, mvuld_stream_t stream);
+int mvuld_mean_pool_bwd(const void* dout, const int* valid, void* dx, int B, int L, int C, int dtype, mvuld_stream_t stream);
+
+/* l2norm over the node axis (no eps) then mean over nodes: GraphModel.py:74-79,201-204 */
+int mvuld_l2norm_mean_fwd(const void* g, void* hf, float* ssum, float* snrm, int B, int Nn, int C, int dtype, mvuld_stream_t stream);
+int mvuld_l2norm_mean_bwd(const void* g, const void* dhf, const float* ssum, const float* snrm, void* dg, int B, int Nn,
+                          int C, int dtype, mvuld_stream_t stream);
+
+/* CrossEntropyLoss + softmax: main_bigvul.py:298,330-333 */
+int mvuld_cross_entropy(const float* logits, const int64_t* target, float* loss, float* probs, float* dlogits, int B,
+                        int K, float loss_scale, mvuld_stream_t stream);
+
+/* GATConv sparse part (dgl 0.8.1 u_add_v / edge_softmax / u_mul_e_sum; GraphModel.py:167-170) over CSR by destination */
+int mvuld_gat_scores_fwd(const void* ft, const float* al, const float* ar, float* el, float* er, int N, int H, int O,
+                         int dtype, mvuld_stream_t stream);
+int mvuld_gat_aggregate_fwd(const void* ft, const float* el, const float* er, const int* indptr_dst, const int* src_by_dst,
+                            const float* bias, void* out, float* alpha, int N, int E, int H, int O, float slope, int dtype,
+                            mvuld_stream_t stream);
+int mvuld_gat_aggregate_bwd(const void* dout, const void* ft, const float* el, const float* er, const float* alpha,
+                            const float* al, const float* ar, const int* indptr_dst, const int* src_by_dst,
+                            const int* indptr_src, const int* dst_by_src, const int* slot_by_src, void* dft, float* dal,
+                            float* dar, float* ws_dlogit, float* ws_der, float* ws_del, int N, int E, int H, int O,
+                            float slope, int dtype, mvuld_stream_t stream);
+
+/* unbatch_features: pad with zero rows / truncate to max_node (GraphModel.py:30-54) */
+int mvuld_segment_pad_fwd(const void* h, const int* node_offsets, void* out, int B, int maxn, int F, int dtype, mvuld_stream_t stream);
+int mvuld_segment_pad_bwd(const void* dout, const int* node_offsets, void* dh, int B, int maxn, int F, int64_t total_nodes,
+                          int dtype, mvuld_stream_t stream);
+
+/* clip_grad_norm_(5.0) + AdamW: utils_multi.py:229-232, optimizer.py:27-31 */
+int mvuld_sumsq(const float* x, int64_t n, float* out, mvuld_stream_t stream);
+int mvuld_clip_coef(const float* sumsq, float max_norm, float* norm_out, mvuld_stream_t stream);
+int mvuld_adamw(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, const float* coef, mvuld_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

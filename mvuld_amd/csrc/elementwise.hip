@@ -1,0 +1,465 @@
+// HBM-bound data-movement / reduction kernels of the hot path (f32|bf16 storage, fp32 math).
+#include "common.h"
+
+#define DISPATCH_T(dtype, CALL)                 \
+    do {                                        \
+        if ((dtype) == MVULD_F32) { typedef float T; CALL; } \
+        else { typedef bf16 T; CALL; }          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ transpose
+// dst[b][c][r] = src[b][r][c]; 64x64 tiles through LDS (padded), coalesced on both sides.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ src, T* __restrict__ dst, int R, int C) {
+    __shared__ float tile[64][65];
+    const int64_t boff = (int64_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? ldf(src + boff + (int64_t)r * C + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) stf(dst + boff + (int64_t)c * R + r, tile[tx][i]);
+    }
+}
+
+extern "C" int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(src && dst && R > 0 && C > 0 && batch > 0, "transpose: bad args");
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), batch);
+    MV_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "transpose: grid too large");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, stream, (const T*)src, (T*)dst, R, C));
+    MV_LAUNCH_CHECK("transpose");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ column sum (bias grads)
+// out[c] += sum_r x[r*ld + c]   (atomic accumulate into fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t M, int N,
+                                                int64_t rows_per_block) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int64_t r = r0 + ty; r < r1; r += 4) s += ldf(x + r * ld + c);
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+extern "C" int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad args");
+    int64_t nby = min((int64_t)512, cdiv(M, 64));
+    const int64_t rpb = cdiv(M, nby);
+    nby = cdiv(M, rpb);
+    dim3 grid((unsigned)cdiv(N, 64), (unsigned)nby);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_k<T>, grid, dim3(256), 0, stream, (const T*)x, ld, out, M, N, rpb));
+    MV_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ activation backward
+// mode 0: GELU(erf), ref = pre-activation.  mode 1: ELU(alpha=1), ref = forward output.
+template <typename T>
+__global__ void act_bwd_k(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ dx, int64_t n, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float r = ldf(ref + i);
+        const float d = mode == 0 ? dgelu_erf(r) : (r > 0.f ? 1.0f : r + 1.0f);
+        stf(dx + i, ldf(dy + i) * d);
+    }
+}
+extern "C" int mvuld_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int mode, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(dy && ref && dx && n > 0 && (mode == 0 || mode == 1), "act_bwd: bad args");
+    const int grid = (int)min((int64_t)4096, cdiv(n, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)ref, (T*)dx, n, mode));
+    MV_LAUNCH_CHECK("act_bwd");
+    return 0;
+}
+
+// elementwise ELU forward (rarely needed outside GEMM epilogues)
+template <typename T>
+__global__ void elu_fwd_k(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        stf(y + i, elu1(ldf(x + i)));
+}
+extern "C" int mvuld_elu_fwd(const void* x, void* y, int64_t n, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && y && n > 0, "elu_fwd: bad args");
+    const int grid = (int)min((int64_t)4096, cdiv(n, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(elu_fwd_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n));
+    MV_LAUNCH_CHECK("elu_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ casts / axpy
+template <typename TI, typename TO>
+__global__ void cast_k(const TI* __restrict__ x, TO* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        stf(y + i, ldf(x + i));
+}
+extern "C" int mvuld_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t n, hipStream_t stream) {
+    MV_CHECK_ARG(x && y && n > 0, "cast: bad args");
+    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
+    if (dtype_in == MVULD_F32 && dtype_out == MVULD_BF16) hipLaunchKernelGGL((cast_k<float, bf16>), dim3(grid), dim3(256), 0, stream, (const float*)x, (bf16*)y, n);
+    else if (dtype_in == MVULD_BF16 && dtype_out == MVULD_F32) hipLaunchKernelGGL((cast_k<bf16, float>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, (float*)y, n);
+    else if (dtype_in == MVULD_F32) hipLaunchKernelGGL((cast_k<float, float>), dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, n);
+    else hipLaunchKernelGGL((cast_k<bf16, bf16>), dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n);
+    MV_LAUNCH_CHECK("cast");
+    return 0;
+}
+
+// y[i] = a[i] + b[i]
+template <typename T>
+__global__ void add_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        stf(y + i, ldf(a + i) + ldf(b + i));
+}
+extern "C" int mvuld_add(const void* a, const void* b, void* y, int64_t n, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(a && b && y && n > 0, "add: bad args");
+    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(add_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)a, (const T*)b, (T*)y, n));
+    MV_LAUNCH_CHECK("add");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ dropout (counter-based, recomputable)
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+// y = x * keep(i) / (1-p), keep(i) = hash(seed, i) >= p.  Same call on the gradient in backward.
+template <typename T>
+__global__ void dropout_k(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed) {
+    const float inv = 1.0f / (1.0f - p);
+    const uint32_t thr = (uint32_t)(p * 4294967296.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool keep = mix32(seed + (uint64_t)i * 0x9E3779B97F4A7C15ULL) >= thr;
+        stf(y + i, keep ? ldf(x + i) * inv : 0.f);
+    }
+}
+extern "C" int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n, p, seed));
+    MV_LAUNCH_CHECK("dropout");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ Swin patch embed im2col
+// img f32 [B,3,S,S] -> cols T [B*(S/4)^2, 48], column = c*16 + ky*4 + kx  (Conv2d weight [E,3,4,4] flattened)
+template <typename T>
+__global__ void im2col4_k(const float* __restrict__ img, T* __restrict__ cols, int B, int S) {
+    const int P = S / 4;
+    const int64_t total = (int64_t)B * P * P * 12;            // one thread per (token, c, ky): 4 contiguous pixels
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % 12);
+        const int64_t tok = i / 12;
+        const int c = ck / 4, ky = ck % 4;
+        const int px = (int)(tok % P), py = (int)((tok / P) % P), b = (int)(tok / ((int64_t)P * P));
+        const float4 v = *(const float4*)(img + (((int64_t)b * 3 + c) * S + py * 4 + ky) * S + px * 4);
+        T* o = cols + tok * 48 + c * 16 + ky * 4;
+        stf(o, v.x); stf(o + 1, v.y); stf(o + 2, v.z); stf(o + 3, v.w);
+    }
+}
+extern "C" int mvuld_im2col_patch4(const float* img, void* cols, int B, int S, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(img && cols && B > 0 && S > 0 && S % 4 == 0, "im2col_patch4: bad args");
+    const int64_t total = (int64_t)B * (S / 4) * (S / 4) * 12;
+    const int grid = (int)min((int64_t)8192, cdiv(total, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(im2col4_k<T>, dim3(grid), dim3(256), 0, stream, img, (T*)cols, B, S));
+    MV_LAUNCH_CHECK("im2col_patch4");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ PatchMerging gather / its inverse
+// forward: y[b, i, j, q*C + c] = x[b, 2i + (q&1), 2j + (q>>1), c]   q = 0..3  (x0,x1,x2,x3 of swin_transformer_v2.py:354-358)
+// inverse (backward): the same index map, copying y -> x.
+template <typename T>
+__global__ void patch_merge_k(const T* __restrict__ src, T* __restrict__ dst, int B, int res, int C, int inverse) {
+    const int h = res / 2;
+    const int64_t total = (int64_t)B * h * h * 4 * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int q = (int)((i / C) % 4);
+        const int64_t t = i / (4 * (int64_t)C);
+        const int j = (int)(t % h), ii = (int)((t / h) % h), b = (int)(t / ((int64_t)h * h));
+        const int64_t xi = (((int64_t)b * res + 2 * ii + (q & 1)) * res + 2 * j + (q >> 1)) * C + c;
+        if (inverse) dst[xi] = src[i];
+        else dst[i] = src[xi];
+    }
+}
+extern "C" int mvuld_patch_merge_gather(const void* src, void* dst, int B, int res, int C, int inverse, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(src && dst && B > 0 && res > 0 && res % 2 == 0 && C > 0, "patch_merge_gather: bad args");
+    const int64_t total = (int64_t)B * res * res * C;
+    const int grid = (int)min((int64_t)8192, cdiv(total, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patch_merge_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)src, (T*)dst, B, res, C, inverse));
+    MV_LAUNCH_CHECK("patch_merge_gather");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ RoBERTa embeddings
+// position ids = cumsum(ids != pad) * (ids != pad) + pad ; valid = ids != pad
+__global__ void position_ids_k(const int64_t* __restrict__ ids, int* __restrict__ pos, int* __restrict__ valid, int B, int L, int pad) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int run = 0;
+    for (int l = 0; l < L; ++l) {
+        const int ok = ids[(int64_t)b * L + l] != pad;
+        run += ok;
+        pos[(int64_t)b * L + l] = ok ? run + pad : pad;
+        valid[(int64_t)b * L + l] = ok;
+    }
+}
+extern "C" int mvuld_position_ids(const int64_t* ids, int* pos, int* valid, int B, int L, int pad, hipStream_t stream) {
+    MV_CHECK_ARG(ids && pos && valid && B > 0 && L > 0, "position_ids: bad args");
+    hipLaunchKernelGGL(position_ids_k, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, stream, ids, pos, valid, B, L, pad);
+    MV_LAUNCH_CHECK("position_ids");
+    return 0;
+}
+
+template <typename T>
+__global__ void embed_fwd_k(const int64_t* __restrict__ ids, const int* __restrict__ pos, const float* __restrict__ word,
+                            const float* __restrict__ posw, const float* __restrict__ type0, T* __restrict__ out, int64_t ntok,
+                            int H, int vocab, int maxpos) {
+    for (int64_t t = blockIdx.x; t < ntok; t += gridDim.x) {
+        int64_t w = ids[t];
+        int p = pos[t];
+        w = w < 0 ? 0 : (w >= vocab ? vocab - 1 : w);
+        p = p < 0 ? 0 : (p >= maxpos ? maxpos - 1 : p);
+        for (int c = threadIdx.x; c < H; c += blockDim.x)
+            stf(out + t * H + c, word[w * H + c] + posw[(int64_t)p * H + c] + type0[c]);
+    }
+}
+template <typename T>
+__global__ void embed_bwd_k(const int64_t* __restrict__ ids, const int* __restrict__ pos, const T* __restrict__ dy,
+                            float* __restrict__ dword, float* __restrict__ dposw, float* __restrict__ dtype0, int64_t ntok, int H,
+                            int vocab, int maxpos) {
+    for (int64_t t = blockIdx.x; t < ntok; t += gridDim.x) {
+        int64_t w = ids[t];
+        int p = pos[t];
+        w = w < 0 ? 0 : (w >= vocab ? vocab - 1 : w);
+        p = p < 0 ? 0 : (p >= maxpos ? maxpos - 1 : p);
+        for (int c = threadIdx.x; c < H; c += blockDim.x) {
+            const float g = ldf(dy + t * H + c);
+            atomicAdd(dword + w * H + c, g);
+            atomicAdd(dposw + (int64_t)p * H + c, g);
+        }
+    }
+}
+extern "C" int mvuld_embed_fwd(const int64_t* ids, const int* pos, const float* word, const float* posw, const float* type0,
+                               void* out, int64_t ntok, int H, int vocab, int maxpos, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(ids && pos && word && posw && type0 && out && ntok > 0 && H > 0, "embed_fwd: bad args");
+    const int grid = (int)min((int64_t)4096, ntok);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_fwd_k<T>, dim3(grid), dim3(256), 0, stream, ids, pos, word, posw, type0, (T*)out, ntok, H, vocab, maxpos));
+    MV_LAUNCH_CHECK("embed_fwd");
+    return 0;
+}
+// dtype0 (token-type row 0) is the column sum of dy: call mvuld_colsum for it.
+extern "C" int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* dword, float* dposw, int64_t ntok, int H,
+                               int vocab, int maxpos, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(ids && pos && dy && dword && dposw && ntok > 0 && H > 0, "embed_bwd: bad args");
+    const int grid = (int)min((int64_t)4096, ntok);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(embed_bwd_k<T>, dim3(grid), dim3(256), 0, stream, ids, pos, (const T*)dy, dword, dposw, nullptr, ntok, H, vocab, maxpos));
+    MV_LAUNCH_CHECK("embed_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ (masked) mean pool over tokens
+// out[b,c] = sum_l x[b,l,c]*m[b,l] / sum_l m[b,l]   (m == null: plain mean; AdaptiveAvgPool1d / unixcoder.py:37)
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_fwd_k(const T* __restrict__ x, const int* __restrict__ valid, T* __restrict__ out,
+                                                       int L, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, n = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float m = valid ? (float)valid[b * L + l] : 1.0f;
+        s += ldf(x + ((int64_t)b * L + l) * C + c) * m;
+        n += m;
+    }
+    stf(out + (int64_t)b * C + c, s / n);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mean_pool_bwd_k(const T* __restrict__ dout, const int* __restrict__ valid, T* __restrict__ dx,
+                                                       int L, int C) {
+    __shared__ float cnt;
+    const int b = blockIdx.z, l = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) {
+        float n = 0.f;
+        if (valid) for (int i = 0; i < L; ++i) n += valid[b * L + i];
+        else n = (float)L;
+        cnt = n;
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const float m = valid ? (float)valid[b * L + l] : 1.0f;
+    stf(dx + ((int64_t)b * L + l) * C + c, ldf(dout + (int64_t)b * C + c) * m / cnt);
+}
+extern "C" int mvuld_mean_pool_fwd(const void* x, const int* valid, void* out, int B, int L, int C, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && out && B > 0 && L > 0 && C > 0, "mean_pool_fwd: bad args");
+    dim3 grid((unsigned)cdiv(C, 256), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mean_pool_fwd_k<T>, grid, dim3(256), 0, stream, (const T*)x, valid, (T*)out, L, C));
+    MV_LAUNCH_CHECK("mean_pool_fwd");
+    return 0;
+}
+extern "C" int mvuld_mean_pool_bwd(const void* dout, const int* valid, void* dx, int B, int L, int C, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(dout && dx && B > 0 && L > 0 && C > 0 && L <= 65535 && B <= 65535, "mean_pool_bwd: bad args");
+    dim3 grid((unsigned)cdiv(C, 256), L, B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mean_pool_bwd_k<T>, grid, dim3(256), 0, stream, (const T*)dout, valid, (T*)dx, L, C));
+    MV_LAUNCH_CHECK("mean_pool_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ l2norm over the node axis + mean over nodes
+// g [B,Nn,C]: nrm[b,c] = sqrt(sum_i g^2) (no eps, GraphModel.py:74-79), hf[b,c] = mean_i g/nrm  (:201-204)
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_mean_fwd_k(const T* __restrict__ g, T* __restrict__ hf, float* __restrict__ ssum,
+                                                         float* __restrict__ snrm, int Nn, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < Nn; ++i) { const float v = ldf(g + ((int64_t)b * Nn + i) * C + c); s += v; q += v * v; }
+    const float nrm = sqrtf(q);
+    ssum[(int64_t)b * C + c] = s; snrm[(int64_t)b * C + c] = nrm;
+    stf(hf + (int64_t)b * C + c, s / (nrm * Nn));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_mean_bwd_k(const T* __restrict__ g, const T* __restrict__ dhf, const float* __restrict__ ssum,
+                                                         const float* __restrict__ snrm, T* __restrict__ dg, int Nn, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float d = ldf(dhf + (int64_t)b * C + c) / Nn, s = ssum[(int64_t)b * C + c], nrm = snrm[(int64_t)b * C + c];
+    const float a = d / nrm, bb = d * s / (nrm * nrm * nrm);
+    for (int i = 0; i < Nn; ++i) {
+        const int64_t o = ((int64_t)b * Nn + i) * C + c;
+        stf(dg + o, a - bb * ldf(g + o));
+    }
+}
+extern "C" int mvuld_l2norm_mean_fwd(const void* g, void* hf, float* ssum, float* snrm, int B, int Nn, int C, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(g && hf && ssum && snrm && B > 0 && Nn > 0 && C > 0, "l2norm_mean_fwd: bad args");
+    dim3 grid((unsigned)cdiv(C, 256), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(l2norm_mean_fwd_k<T>, grid, dim3(256), 0, stream, (const T*)g, (T*)hf, ssum, snrm, Nn, C));
+    MV_LAUNCH_CHECK("l2norm_mean_fwd");
+    return 0;
+}
+extern "C" int mvuld_l2norm_mean_bwd(const void* g, const void* dhf, const float* ssum, const float* snrm, void* dg, int B, int Nn, int C,
+                                     int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(g && dhf && ssum && snrm && dg && B > 0 && Nn > 0 && C > 0, "l2norm_mean_bwd: bad args");
+    dim3 grid((unsigned)cdiv(C, 256), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(l2norm_mean_bwd_k<T>, grid, dim3(256), 0, stream, (const T*)g, (const T*)dhf, ssum, snrm, (T*)dg, Nn, C));
+    MV_LAUNCH_CHECK("l2norm_mean_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ softmax + cross-entropy (fp32 logits)
+// loss += mean_b -log softmax(logits[b])[target[b]] * loss_scale ; probs = softmax ; dlogits = (probs - onehot) * loss_scale / B
+__global__ void ce_k(const float* __restrict__ logits, const int64_t* __restrict__ target, float* __restrict__ loss,
+                     float* __restrict__ probs, float* __restrict__ dlogits, int B, int K, float loss_scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logits[b * K + k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(logits[b * K + k] - m);
+    const int t = (int)target[b];
+    for (int k = 0; k < K; ++k) {
+        const float p = expf(logits[b * K + k] - m) / s;
+        if (probs) probs[b * K + k] = p;
+        if (dlogits) dlogits[b * K + k] = (p - (k == t ? 1.f : 0.f)) * loss_scale / B;
+    }
+    atomicAdd(loss, (logf(s) + m - logits[b * K + t]) * loss_scale / B);
+}
+extern "C" int mvuld_cross_entropy(const float* logits, const int64_t* target, float* loss, float* probs, float* dlogits, int B, int K,
+                                   float loss_scale, hipStream_t stream) {
+    MV_CHECK_ARG(logits && target && loss && B > 0 && K > 0, "cross_entropy: bad args");
+    hipLaunchKernelGGL(ce_k, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, stream, logits, target, loss, probs, dlogits, B, K, loss_scale);
+    MV_LAUNCH_CHECK("cross_entropy");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ Swin continuous position bias table
+// table16[i,h] = 16*sigmoid( W2[h,:] . relu(W1 . coords[i] + b1) )   coords [T2,2], W1 [512,2], b1 [512], W2 [H,512]
+// (swin_transformer_v2.py:159-163).  hidden [T2,512] is kept for the backward.
+__global__ __launch_bounds__(256) void cpb_fwd_k(const float* __restrict__ coords, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                 const float* __restrict__ W2, float* __restrict__ hidden, float* __restrict__ table16,
+                                                 int T2, int H) {
+    __shared__ float hid[512];
+    __shared__ float red[16];
+    const int i = blockIdx.x;
+    const float cy = coords[2 * i], cx = coords[2 * i + 1];
+    for (int j = threadIdx.x; j < 512; j += 256) {
+        const float v = fmaxf(W1[2 * j] * cy + W1[2 * j + 1] * cx + b1[j], 0.f);
+        hid[j] = v;
+        hidden[(int64_t)i * 512 + j] = v;
+    }
+    __syncthreads();
+    for (int h = 0; h < H; ++h) {
+        float s = hid[threadIdx.x] * W2[h * 512 + threadIdx.x] + hid[threadIdx.x + 256] * W2[h * 512 + threadIdx.x + 256];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) table16[(int64_t)i * H + h] = 16.0f / (1.0f + __expf(-s));
+    }
+}
+// dz[i,h] = dtable16 * t16*(1 - t16/16);  dW2[h,j] += dz*hid[i,j];  dhid[j] = sum_h dz*W2[h,j] (relu gate);
+// dW1[j,:] += dhid*coords[i];  db1[j] += dhid.   One block per chunk of CPB_ROWS table rows; thread <-> hidden
+// units j and j+256; per-block partials leave through fp32 atomics.
+#define CPB_ROWS 32
+#define CPB_MAXH 32
+__global__ __launch_bounds__(256) void cpb_bwd_k(const float* __restrict__ coords, const float* __restrict__ W2, const float* __restrict__ hidden,
+                                                 const float* __restrict__ table16, const float* __restrict__ dtable16,
+                                                 float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, int T2, int H) {
+    __shared__ float dz[CPB_ROWS][CPB_MAXH];
+    __shared__ float cy[CPB_ROWS], cx[CPB_ROWS];
+    const int i0 = blockIdx.x * CPB_ROWS;
+    const int nrow = min(CPB_ROWS, T2 - i0);
+    for (int e = threadIdx.x; e < CPB_ROWS * CPB_MAXH; e += 256) {
+        const int r = e / CPB_MAXH, h = e % CPB_MAXH;
+        float v = 0.f;
+        if (r < nrow && h < H) {
+            const float t = table16[(int64_t)(i0 + r) * H + h];
+            v = dtable16[(int64_t)(i0 + r) * H + h] * t * (1.0f - t * 0.0625f);
+        }
+        dz[r][h] = v;
+    }
+    if (threadIdx.x < CPB_ROWS) {
+        const int r = threadIdx.x;
+        cy[r] = r < nrow ? coords[2 * (i0 + r)] : 0.f;
+        cx[r] = r < nrow ? coords[2 * (i0 + r) + 1] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = threadIdx.x + half * 256;
+        float w2[CPB_MAXH], acc2[CPB_MAXH];
+#pragma unroll
+        for (int h = 0; h < CPB_MAXH; ++h) { w2[h] = h < H ? W2[h * 512 + j] : 0.f; acc2[h] = 0.f; }
+        float a0 = 0.f, a1 = 0.f, ab = 0.f;
+        for (int r = 0; r < nrow; ++r) {
+            const float hv = hidden[(int64_t)(i0 + r) * 512 + j];
+            float dh = 0.f;
+#pragma unroll
+            for (int h = 0; h < CPB_MAXH; ++h) { acc2[h] = fmaf(dz[r][h], hv, acc2[h]); dh = fmaf(dz[r][h], w2[h], dh); }
+            if (hv > 0.f) { a0 += dh * cy[r]; a1 += dh * cx[r]; ab += dh; }
+        }
+#pragma unroll
+        for (int h = 0; h < CPB_MAXH; ++h)
+            if (h < H) atomicAdd(dW2 + h * 512 + j, acc2[h]);
+        atomicAdd(dW1 + 2 * j, a0); atomicAdd(dW1 + 2 * j + 1, a1); atomicAdd(db1 + j, ab);
+    }
+}
+extern "C" int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden, float* table16,
+                                   int T2, int H, hipStream_t stream) {
+    MV_CHECK_ARG(coords && W1 && b1 && W2 && hidden && table16 && T2 > 0 && H > 0, "cpb_table_fwd: bad args");
+    hipLaunchKernelGGL(cpb_fwd_k, dim3(T2), dim3(256), 0, stream, coords, W1, b1, W2, hidden, table16, T2, H);
+    MV_LAUNCH_CHECK("cpb_table_fwd");
+    return 0;
+}
+extern "C" int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16, const float* dtable16,
+                                   float* dW1, float* db1, float* dW2, int T2, int H, hipStream_t stream) {
+    MV_CHECK_ARG(coords && W2 && hidden && table16 && dtable16 && dW1 && db1 && dW2 && T2 > 0 && H > 0 && H <= CPB_MAXH, "cpb_table_bwd: bad args (H<=32)");
+    hipLaunchKernelGGL(cpb_bwd_k, dim3((unsigned)cdiv(T2, CPB_ROWS)), dim3(256), 0, stream, coords, W2, hidden, table16, dtable16, dW1, db1, dW2, T2, H);
+    MV_LAUNCH_CHECK("cpb_table_bwd");
+    return 0;
+}

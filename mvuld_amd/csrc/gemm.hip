@@ -1,0 +1,315 @@
+// GEMM family of libmvuld_hip.so:  C[b] = epilogue(alpha * A[b] . B[b]^T)   ("NT": both operands K-contiguous)
+//
+//   * gemm_nt_mfma_bf16 : bf16 operands, fp32 accumulate on the CDNA4 matrix cores
+//     (v_mfma_f32_16x16x32_bf16), 128x128x64 tiles, 4 waves (2x2, 64x64 per wave),
+//     register-staged double-buffered LDS with an XOR chunk swizzle, LDS-staged
+//     row-major epilogue (bias / GELU / ELU / activation-derivative / split-K atomics).
+//   * gemm_nt_simple    : any (f32|bf16) operands, VALU fp32 FMA, 64x64x16 tiles.  The
+//     fp32 parity path and the odd-shaped GEMMs of the head (K or ld not 16-byte friendly).
+//
+// Every Linear / Conv1d(k=1) / Conv2d(4x4,s4) / batched bmm of the hot path lands here:
+//   Swin qkv/proj/fc1/fc2/reduction/patch-embed (swin_transformer_v2.py:150,177,27-30,361,490),
+//   RoBERTa q/k/v/out/intermediate/output dense, GATConv fc, head Linear layers
+//   (GraphModel.py:153-209) and Rs_GCN's 1x1 convs + theta^T.phi / R.g (Rs_GCN.py:57-70).
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6 };
+enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_ATOMIC = 2 };
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    int64_t lda, ldb, ldc, sA, sB, sC;     // leading dims and batch strides, in elements
+    int M, N, K, batch, splitk;
+    const float* bias;                     // [N] or null
+    void* aux; int64_t ldaux, sAux;        // pre-activation (GELU out / dGELU in) or ELU output (dELU in); dtype of C
+    float alpha; int epi; int out_mode;
+};
+
+template <typename TO>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, TO* C, TO* aux, int row, int col, float acc) {
+    float v = g.alpha * acc;
+    if (g.bias) v += g.bias[col];
+    const int64_t ci = (int64_t)row * g.ldc + col;
+    const int64_t ai = (int64_t)row * g.ldaux + col;
+    switch (g.epi) {
+        case EPI_GELU:
+            if (aux) stf(aux + ai, v);
+            v = gelu_erf(v);
+            break;
+        case EPI_ELU: v = elu1(v); break;
+        case EPI_MUL_DGELU: v *= dgelu_erf(ldf(aux + ai)); break;
+        case EPI_MUL_DELU: { const float y = ldf(aux + ai); v *= (y > 0.f ? 1.0f : y + 1.0f); } break;
+        case EPI_ADD_AUX: v += ldf(aux + ai); break;
+        default: break;
+    }
+    if (g.out_mode == OUT_ATOMIC) {
+        if constexpr (sizeof(TO) == 4) atomicAdd((float*)(C + ci), v);
+    } else if (g.out_mode == OUT_ACCUM) {
+        stf(C + ci, ldf(C + ci) + v);
+    } else {
+        stf(C + ci, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------ simple
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_simple(GemmArgs g) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int bz = blockIdx.z;
+    const int b = bz / g.splitk, ks = bz % g.splitk;
+    const TI* A = (const TI*)g.A + (int64_t)b * g.sA;
+    const TI* B = (const TI*)g.B + (int64_t)b * g.sB;
+    TO* C = (TO*)g.C + (int64_t)b * g.sC;
+    TO* aux = g.aux ? (TO*)g.aux + (int64_t)b * g.sAux : nullptr;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int lr = t >> 2, lk = (t & 3) * 4;
+    const int ktiles = (g.K + 15) / 16;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+    float acc[4][4] = {};
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int k0 = kt * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + lk + j;
+            const int ra = m0 + lr, rb = n0 + lr;
+            As[lk + j][lr] = (ra < g.M && k < g.K) ? ldf(A + (int64_t)ra * g.lda + k) : 0.f;
+            Bs[lk + j][lr] = (rb < g.N && k < g.K) ? ldf(B + (int64_t)rb * g.ldb + k) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; bb[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    if (kt0 >= kt1 && g.out_mode == OUT_ATOMIC) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m0 + ty * 4 + i, c = n0 + tx * 4 + j;
+            if (r < g.M && c < g.N) epilogue_store<TO>(g, C, aux, r, c, acc[i][j]);
+        }
+}
+
+// ------------------------------------------------------------------------------------ MFMA bf16
+typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
+typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+
+#define GT_BM 128
+#define GT_BN 128
+#define GT_BK 64
+#define GT_LDS_MAIN (2 * 2 * GT_BM * GT_BK * 2)       // 64 KiB: {A,B} x 2 buffers
+#define GT_EPI_LD 68
+#define GT_LDS_EPI (4 * 64 * GT_EPI_LD * 4)           // 69632 B: per-wave 64x64 fp32 staging
+#define GT_LDS_BYTES (GT_LDS_EPI > GT_LDS_MAIN ? GT_LDS_EPI : GT_LDS_MAIN)
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [128][64] bf16 tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles, walked N-fastest so neighbours reuse the same A row panel.
+    const int nt = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nt >> 3, r = nt & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * GT_BM, n0 = tn * GT_BN;
+    const int bz = blockIdx.y;
+    const int b = bz / g.splitk, ks = bz % g.splitk;
+    const bf16* A = (const bf16*)g.A + (int64_t)b * g.sA;
+    const bf16* B = (const bf16*)g.B + (int64_t)b * g.sB;
+    TO* C = (TO*)g.C + (int64_t)b * g.sC;
+    TO* aux = g.aux ? (TO*)g.aux + (int64_t)b * g.sAux : nullptr;
+
+    const int ktiles = (g.K + GT_BK - 1) / GT_BK;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1 && g.out_mode == OUT_ATOMIC) return;
+
+    // staging map: 1024 16-byte chunks per operand tile, 4 per thread
+    int s_row[4], s_ch[4];
+    const bf16* a_ptr[4];
+    const bf16* b_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        s_row[i] = c >> 3; s_ch[i] = c & 7;
+        a_ptr[i] = A + (int64_t)min(m0 + s_row[i], g.M - 1) * g.lda + s_ch[i] * 8;
+        b_ptr[i] = B + (int64_t)min(n0 + s_row[i], g.N - 1) * g.ldb + s_ch[i] * 8;
+    }
+    uint4 ra[4], rb[4];
+    auto stage_load = [&](int kt) {
+        const int k0 = kt * GT_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (k0 + s_ch[i] * 8) < g.K;
+            ra[i] = ok ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+            rb[i] = ok ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        char* sa = smem + buf * 32768;
+        char* sb = sa + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = swz_off(s_row[i], s_ch[i]);
+            *(uint4*)(sa + off) = ra[i];
+            *(uint4*)(sb + off) = rb[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        stage_load(kt0);
+        stage_write(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) stage_load(kt + 1);
+        const char* sa = smem + cur * 32768;
+        const char* sb = sa + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *(const bf16x8_t*)(sa + swz_off(wr * 64 + i * 16 + fr, kk * 4 + fg));
+                fb[i] = *(const bf16x8_t*)(sb + swz_off(wc * 64 + i * 16 + fr, kk * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS tile -> row-major 16-byte-per-lane pass
+    float* ep = (float*)(smem + wave * (64 * GT_EPI_LD * 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const bool vec_ok = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.out_mode == OUT_STORE) &&
+                        (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_ELU || g.epi == EPI_GELU) &&
+                        (g.ldaux % 4 == 0);
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int lr = p * 4 + fg, lc = fr * 4;
+        const int row = m0 + wr * 64 + lr, col = n0 + wc * 64 + lc;
+        if (row >= g.M || col >= g.N) continue;
+        const float4 v4 = *(const float4*)(ep + lr * GT_EPI_LD + lc);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (vec_ok) {
+            float pre[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = g.alpha * v[e];
+                if (g.bias) x += g.bias[col + e];
+                pre[e] = x;
+                if (g.epi == EPI_GELU) x = gelu_erf(x);
+                else if (g.epi == EPI_ELU) x = elu1(x);
+                v[e] = x;
+            }
+            TO* cp = C + (int64_t)row * g.ldc + col;
+            if constexpr (sizeof(TO) == 4) {
+                *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.epi == EPI_GELU && aux)
+                    *(float4*)(aux + (int64_t)row * g.ldaux + col) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+            } else {
+                bf16x4 o; o.v[0] = (bf16)v[0]; o.v[1] = (bf16)v[1]; o.v[2] = (bf16)v[2]; o.v[3] = (bf16)v[3];
+                *(bf16x4*)cp = o;
+                if (g.epi == EPI_GELU && aux) {
+                    bf16x4 q; q.v[0] = (bf16)pre[0]; q.v[1] = (bf16)pre[1]; q.v[2] = (bf16)pre[2]; q.v[3] = (bf16)pre[3];
+                    *(bf16x4*)(aux + (int64_t)row * g.ldaux + col) = q;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < g.N) epilogue_store<TO>(g, C, aux, row, col + e, v[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
+                             void* C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
+                             const float* bias, int epilogue, void* aux, int64_t ldaux, int64_t strideAux,
+                             float alpha, int out_mode, int splitk, int dtype_in, int dtype_out, int force_simple,
+                             hipStream_t stream) {
+    MV_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_nt: empty problem M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    MV_CHECK_ARG(A && B && C, "gemm_nt: null operand");
+    MV_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_ADD_AUX, "gemm_nt: bad epilogue %d", epilogue);
+    MV_CHECK_ARG(!((epilogue >= EPI_MUL_DGELU) && !aux), "gemm_nt: epilogue %d needs aux", epilogue);
+    MV_CHECK_ARG(out_mode >= OUT_STORE && out_mode <= OUT_ATOMIC, "gemm_nt: bad out_mode %d", out_mode);
+    MV_CHECK_ARG(!(out_mode == OUT_ATOMIC && dtype_out != MVULD_F32), "gemm_nt: atomic output must be f32");
+    MV_CHECK_ARG(!(out_mode == OUT_ATOMIC && epilogue > EPI_BIAS), "gemm_nt: atomic output with nonlinear epilogue");
+    if (splitk < 1) splitk = 1;
+    MV_CHECK_ARG(splitk == 1 || out_mode == OUT_ATOMIC, "gemm_nt: split-K needs atomic output");
+    MV_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dim too small");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.splitk = splitk; g.bias = bias; g.aux = aux; g.ldaux = ldaux;
+    g.sAux = strideAux; g.alpha = alpha; g.epi = epilogue; g.out_mode = out_mode;
+    const bool aligned = (K % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (strideA % 8 == 0) && (strideB % 8 == 0) &&
+                         (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+    const bool use_mfma = (dtype_in == MVULD_BF16) && aligned && !force_simple && (M >= 32) && (N >= 32);
+    if (use_mfma) {
+        const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(N, GT_BN);
+        dim3 grid(tiles_m * tiles_n, batch * splitk);
+        if (dtype_out == MVULD_F32) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES); attr = true; }
+            hipLaunchKernelGGL(gemm_nt_mfma_bf16<float>, grid, dim3(256), GT_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        } else {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES); attr = true; }
+            hipLaunchKernelGGL(gemm_nt_mfma_bf16<bf16>, grid, dim3(256), GT_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        }
+        MV_LAUNCH_CHECK("gemm_nt_mfma_bf16");
+        return 0;
+    }
+    dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), batch * splitk);
+    MV_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "gemm_nt: grid too large for the simple kernel (M=%d)", M);
+    if (dtype_in == MVULD_F32 && dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_simple<float, float>), grid, dim3(256), 0, stream, g);
+    else if (dtype_in == MVULD_BF16 && dtype_out == MVULD_BF16) hipLaunchKernelGGL((gemm_nt_simple<bf16, bf16>), grid, dim3(256), 0, stream, g);
+    else if (dtype_in == MVULD_BF16 && dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_simple<bf16, float>), grid, dim3(256), 0, stream, g);
+    else if (dtype_in == MVULD_F32 && dtype_out == MVULD_BF16) hipLaunchKernelGGL((gemm_nt_simple<float, bf16>), grid, dim3(256), 0, stream, g);
+    else { mvuld_set_error("gemm_nt: bad dtypes %d %d", dtype_in, dtype_out); return 1; }
+    MV_LAUNCH_CHECK("gemm_nt_simple");
+    return 0;
+}

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libmvuld_hip.so`` (C ABI declared in ``include/mvuld_hip.h``).
+
+Prototypes are parsed from the header itself, so the binding cannot drift from the
+declared ABI.  There is NO fallback: if the library is missing or a call fails, the
+product path raises -- nothing here routes to PyTorch compute or to ``oracle/``.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvuld_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mvuld_hip.h")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_ELU, EPI_MUL_DGELU, EPI_MUL_DELU, EPI_ADD_AUX = range(7)
+OUT_STORE, OUT_ACCUM, OUT_ATOMIC = range(3)
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
+    "mvuld_stream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """{name: (restype, [argtypes])} for every ``mvuld_*`` prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(mvuld_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const ", "").split(" ")[0]
+                    argtypes.append(_CT[base])
+        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, argtypes)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+        self._protos = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"mvuld_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(make -C mvuld_amd/csrc).  There is no CPU / PyTorch fallback for the hot path.")
+            self._dll = ctypes.CDLL(LIB_PATH)
+            self._protos = parse_header()
+            for name, (ret, argtypes) in self._protos.items():
+                fn = getattr(self._dll, name)         # AttributeError => header/library drift
+                fn.restype = ret
+                fn.argtypes = argtypes
+        return self._dll
+
+    def fn(self, name):
+        return getattr(self.load(), name)
+
+
+LIB = _Lib()
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def last_error() -> str:
+    return LIB.fn("mvuld_last_error")().decode()
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"mvuld_amd: unsupported activation dtype {t.dtype}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke ``mvuld_<name>`` on the current stream; raise on a non-zero status."""
+    fn = LIB.fn("mvuld_" + name)
+    rc = fn(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"mvuld_{name} failed ({rc}): {last_error()}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mvuld_amd: the hot path runs only on the GPU through libmvuld_hip.so "
+                               "(got a CPU tensor; there is no CPU fallback)")

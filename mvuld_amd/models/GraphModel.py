@@ -1,0 +1,350 @@
+"""Graph / fusion head on libmvuld_hip.so: ``Multi_DefectModel_new_GCN`` with the reference's constructor,
+``forward(g, img_embedding, func_text_embedding)`` and state_dict keys (mvuld/models/GraphModel.py:81-211).
+
+Execution differences (results identical up to float rounding):
+* ``GATConv`` (dgl 0.8.1, third party) is this file's module over CSR-by-destination kernels;
+* ``unbatch_features`` (:30-54, a Python loop over ``dgl.unbatch`` + ``torch.cat``) is one segmented pad kernel;
+* the Rs_GCN chain runs on node rows ``[B*100, 512]`` -- no permutes (:190,:200);
+* the dead ``h_func`` branch (:172,:177: never reaches the logits) is not computed; ``fconly``, ``ln_text``,
+  ``hbn``, ``hln``, ``hfc`` stay as (unused) parameters exactly as in the reference.
+``g`` is a ``mvuld_amd.graph.BatchedGraph`` (the dgl stand-in); ``g.ndata['HGATOUTPUT'/'HFGATOUTPUT']`` are set
+as in the reference (:180-181).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F   # noqa: F401  (API parity; no torch compute is used on the path)
+
+from .. import hip, ops
+from ..hip import call, ptr, dt
+from .Rs_GCN import Rs_GCN
+
+_SEED = [0x5EED]
+
+
+def _next_seed():
+    _SEED[0] = (_SEED[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _SEED[0]
+
+
+# ------------------------------------------------------------------------------------------------ functions
+class _LinearActFn(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)); act in {None, 'elu'}."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, out_dtype, p_drop, training):
+        hip.require_gpu(x)
+        ad = x.dtype
+        x2 = x.reshape(-1, x.shape[-1])
+        w2 = ops.weight(w, ad).reshape(w.shape[0], -1)
+        y = ops.gemm_nt(x2, w2, bias=None if b is None else b.data, epi=hip.EPI_ELU if act == "elu" else hip.EPI_NONE,
+                        out_dtype=out_dtype or ad)
+        seed = 0
+        out = y
+        if training and p_drop > 0:
+            seed = _next_seed()
+            out = ops.dropout(y, p_drop, seed)
+        ctx.save_for_backward(x2, y)
+        ctx.meta = (w, b, act, p_drop if training else 0.0, seed, x.shape, ad)
+        return out.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, y = ctx.saved_tensors
+        w, b, act, p, seed, xshape, ad = ctx.meta
+        d = dout.reshape(-1, dout.shape[-1]).contiguous()
+        if d.dtype != ad:
+            d = ops.cast(d, ad)
+        if p > 0:
+            d = ops.dropout(d, p, seed)
+        if act == "elu":
+            d = ops.act_bwd(d, y, 1)
+        ops.linear_wgrad(d, x2, w, b)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(d, ops.weight_t(w, ad)).view(xshape)
+        return dx, None, None, None, None, None, None
+
+
+def linear_act(x, w, b, act=None, out_dtype=None, p_drop=0.0, training=False):
+    return _LinearActFn.apply(x, w, b, act, out_dtype, p_drop, training)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """BatchNorm1d over dim 1 of [B,C] or [B,C,F] (channel = dim 1), batch statistics when training."""
+
+    @staticmethod
+    def forward(ctx, x, bn):
+        hip.require_gpu(x)
+        x = x.contiguous()
+        if x.dim() == 2:
+            O, C, I = x.shape[0], x.shape[1], 1
+            so, sc, si = C, 1, 1
+        else:
+            O, C, I = x.shape
+            so, sc, si = C * I, I, 1
+        training = bn.training
+        y, sm, sr = ops.batchnorm_fwd(x, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, O, C, I, so, sc, si,
+                                      training, bn.eps, bn.momentum)
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, sm, sr)
+        ctx.meta = (bn, (O, C, I, so, sc, si), training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sm, sr = ctx.saved_tensors
+        bn, lay, training = ctx.meta
+        return ops.batchnorm_bwd(dy.contiguous(), x, bn.weight, bn.bias, sm, sr, *lay, training), None
+
+
+class _GATConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, conv, index, training):
+        hip.require_gpu(x)
+        ad = x.dtype
+        N = x.shape[0]
+        H, O = conv._num_heads, conv._out_feats
+        seed, p = 0, (conv.feat_drop_p if training else 0.0)
+        xin = x
+        if p > 0:
+            seed = _next_seed()
+            xin = ops.dropout(x, p, seed)
+        ft = ops.gemm_nt(xin, ops.weight(conv.fc.weight, ad))                       # [N, H*O]
+        el = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        er = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        call("gat_scores_fwd", ptr(ft), ptr(conv.attn_l), ptr(conv.attn_r), ptr(el), ptr(er), N, H, O, dt(ft))
+        E = index["src_by_dst"].numel()
+        alpha = torch.empty((max(E, 1), H), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, H, O), dtype=ad, device=x.device)
+        call("gat_aggregate_fwd", ptr(ft), ptr(el), ptr(er), ptr(index["indptr_dst"]), ptr(index["src_by_dst"]),
+             ptr(conv.bias), ptr(out), ptr(alpha), N, E, H, O, conv.negative_slope, dt(ft))
+        ctx.save_for_backward(xin, ft, el, er, alpha)
+        ctx.meta = (conv, index, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, ft, el, er, alpha = ctx.saved_tensors
+        conv, index, p, seed = ctx.meta
+        ad = xin.dtype
+        N = xin.shape[0]
+        H, O = conv._num_heads, conv._out_feats
+        E = index["src_by_dst"].numel()
+        dout = dout.contiguous()
+        ops.colsum_into(dout.view(N, H * O), ops.grad_of(conv.bias))
+        dft = torch.empty_like(ft)
+        dev = xin.device
+        ws1 = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
+        ws2 = torch.empty((N, H), dtype=torch.float32, device=dev)
+        ws3 = torch.empty((N, H), dtype=torch.float32, device=dev)
+        call("gat_aggregate_bwd", ptr(dout), ptr(ft), ptr(el), ptr(er), ptr(alpha), ptr(conv.attn_l), ptr(conv.attn_r),
+             ptr(index["indptr_dst"]), ptr(index["src_by_dst"]), ptr(index["indptr_src"]), ptr(index["dst_by_src"]),
+             ptr(index["slot_by_src"]), ptr(dft), ptr(ops.grad_of(conv.attn_l)), ptr(ops.grad_of(conv.attn_r)),
+             ptr(ws1), ptr(ws2), ptr(ws3), N, E, H, O, conv.negative_slope, dt(ft))
+        ops.linear_wgrad(dft, xin, conv.fc.weight, None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dft, ops.weight_t(conv.fc.weight, ad))
+            if p > 0:
+                dx = ops.dropout(dx, p, seed)
+        return dx, None, None, None
+
+
+class _SegmentPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, offsets, B, maxn):
+        h = h.contiguous()
+        F_ = h.shape[1]
+        out = torch.empty((B, maxn, F_), dtype=h.dtype, device=h.device)
+        call("segment_pad_fwd", ptr(h), ptr(offsets), ptr(out), B, maxn, F_, dt(h))
+        ctx.save_for_backward(offsets)
+        ctx.meta = (B, maxn, F_, h.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (offsets,) = ctx.saved_tensors
+        B, maxn, F_, ntot = ctx.meta
+        dh = torch.empty((ntot, F_), dtype=dout.dtype, device=dout.device)
+        dout = dout.contiguous()
+        call("segment_pad_bwd", ptr(dout), ptr(offsets), ptr(dh), B, maxn, F_, ntot, dt(dh))
+        return dh, None, None, None
+
+
+class _L2NormMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, B):
+        """g [B*Nn, C] node rows -> [B, C]."""
+        C = g.shape[1]
+        Nn = g.shape[0] // B
+        hf = torch.empty((B, C), dtype=g.dtype, device=g.device)
+        ssum = torch.empty((B, C), dtype=torch.float32, device=g.device)
+        snrm = torch.empty((B, C), dtype=torch.float32, device=g.device)
+        call("l2norm_mean_fwd", ptr(g), ptr(hf), ptr(ssum), ptr(snrm), B, Nn, C, dt(g))
+        ctx.save_for_backward(g, ssum, snrm)
+        ctx.meta = (B, Nn, C)
+        return hf
+
+    @staticmethod
+    def backward(ctx, dhf):
+        g, ssum, snrm = ctx.saved_tensors
+        B, Nn, C = ctx.meta
+        dg = torch.empty_like(g)
+        dhf = dhf.contiguous()
+        call("l2norm_mean_bwd", ptr(g), ptr(dhf), ptr(ssum), ptr(snrm), ptr(dg), B, Nn, C, dt(g))
+        return dg, None
+
+
+class _ConcatColsFn(torch.autograd.Function):
+    """cat along the last dim through device copies (memory movement only)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        widths = [x.shape[-1] for x in xs]
+        out = torch.empty(xs[0].shape[:-1] + (sum(widths),), dtype=xs[0].dtype, device=xs[0].device)
+        o = 0
+        for x, w in zip(xs, widths):
+            out[..., o:o + w].copy_(x)
+            o += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(d[..., o:o + w].contiguous())
+            o += w
+        return tuple(outs)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, loss_scale):
+        hip.require_gpu(logits)
+        assert logits.dtype == torch.float32
+        B, K = logits.shape
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        probs = torch.empty_like(logits)
+        dlog = torch.empty_like(logits)
+        logits, target = logits.contiguous(), target.contiguous()
+        call("cross_entropy", ptr(logits), ptr(target), ptr(loss), ptr(probs), ptr(dlog), B, K, float(loss_scale))
+        ctx.save_for_backward(dlog)
+        ctx.mark_non_differentiable(probs)
+        return loss, probs
+
+    @staticmethod
+    def backward(ctx, dloss, _dp):
+        # the upstream factor is taken to be 1 (loss.backward()); scale through `loss_scale` instead, so that no
+        # host sync / torch arithmetic is needed here
+        (dlog,) = ctx.saved_tensors
+        return dlog, None, None
+
+
+def cross_entropy(logits, target, loss_scale=1.0):
+    """(mean CE * loss_scale, softmax probs): CrossEntropyLoss + F.softmax of main_bigvul.py:298,330-333."""
+    return _CrossEntropyFn.apply(logits, target, loss_scale)
+
+
+# ------------------------------------------------------------------------------------------------ modules
+class GATConv(nn.Module):
+    """dgl.nn.pytorch.GATConv(in_feats, out_feats, num_heads, feat_drop) with dgl's parameter names."""
+
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2, residual=False,
+                 activation=None, allow_zero_in_degree=False, bias=True):
+        super().__init__()
+        assert attn_drop == 0.0 and not residual and activation is None and bias
+        self._in_feats, self._out_feats, self._num_heads = in_feats, out_feats, num_heads
+        self.negative_slope = negative_slope
+        self.feat_drop_p = float(feat_drop)
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.bias = nn.Parameter(torch.zeros(num_heads * out_feats))
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+
+    def forward(self, graph, feat):
+        return _GATConvFn.apply(feat, self, graph.index(), self.training)
+
+
+def l2norm(X):
+    """L2-normalise over dim 1 (reference helper, GraphModel.py:74-79); fused with the mean on the hot path."""
+    raise RuntimeError("l2norm is fused into _L2NormMeanFn on the hot path")
+
+
+class Multi_DefectModel_new_GCN(nn.Module):
+    '''best model (reference GraphModel.py:81-211)'''
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_features = 1024
+        self.config = config
+        self.num_classes = config.MODEL.NUM_CLASSES
+        self.act_dtype = act_dtype
+        hfeat, embfeat, numheads = 512, 768, 4
+        self.p_gat, self.p_mlp, self.p_hidden = 0.2, 0.2, 0.2
+        self.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+        self.gat2 = GATConv(in_feats=hfeat * numheads, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+        self.fc = nn.Linear(hfeat * numheads, hfeat)
+        self.fconly = nn.Linear(embfeat, hfeat)
+        self.hidden = nn.ModuleList([nn.Linear(hfeat, hfeat) for _ in range(8)])
+        for i in range(1, 9):
+            setattr(self, f"Rs_GCN_{i}", Rs_GCN(in_channels=512, inter_channels=512))
+        self.bn_text = nn.BatchNorm1d(embfeat)
+        self.ln_text = nn.LayerNorm(embfeat)
+        self.fc_text = nn.Linear(embfeat, hfeat)
+        self.max_node = 100
+        self.bn_gat = nn.BatchNorm1d(self.max_node)
+        self.fc_gat = nn.Linear(512, 480)
+        self.bn_bbox = nn.BatchNorm1d(self.max_node)
+        self.fc_bbox = nn.Linear(4, 32)
+        self.swinbn = nn.BatchNorm1d(self.num_features)
+        self.swinfc = nn.Linear(self.num_features, hfeat)
+        self.hbn = nn.BatchNorm1d(hfeat)
+        self.hln = nn.LayerNorm(hfeat)
+        self.hfc = nn.Linear(hfeat, hfeat)
+        self.final_fc = nn.Linear(hfeat * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(hfeat * 3)
+        # parameters the reference constructs but never uses in forward (hence find_unused_parameters=True there)
+        self.unused_parameter_prefixes = ("fconly.", "ln_text.", "hbn.", "hln.", "hfc.")
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad = self.act_dtype
+        tr = self.training
+        hip.require_gpu(img_embedding, func_text_embedding)
+        B = g.batch_size
+        img_embedding = ops.cast(img_embedding.contiguous(), ad) if img_embedding.dtype != ad else img_embedding
+        func_text_embedding = ops.cast(func_text_embedding.contiguous(), ad) if func_text_embedding.dtype != ad else func_text_embedding
+        # 1. image branch  (:153-154)
+        x = linear_act(_BatchNormFn.apply(img_embedding, self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        # 2. text branch   (:158-159)
+        t = linear_act(_BatchNormFn.apply(func_text_embedding, self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        # 3. graph branch  (:163-177)
+        h = g.ndata["_UNIX_NODE_EMB"]
+        bboxes = g.ndata["pos_emb"]
+        h = ops.cast(h.contiguous(), ad) if h.dtype != ad else h
+        bboxes = ops.cast(bboxes.contiguous(), ad) if bboxes.dtype != ad else bboxes
+        h = self.gat(g, h).view(h.shape[0], -1)
+        h = self.gat2(g, h).view(h.shape[0], -1)
+        h = linear_act(h, self.fc.weight, self.fc.bias, "elu", None, self.p_mlp, tr)
+        for hl in self.hidden:
+            h = linear_act(h, hl.weight, hl.bias, "elu", None, self.p_hidden, tr)
+        g.ndata['HGATOUTPUT'] = h
+        g.ndata['HFGATOUTPUT'] = bboxes
+        # unbatch + pad/truncate to 100 nodes  (:182-184)
+        off = g.index()["node_offsets"]
+        h_i = _SegmentPadFn.apply(h, off, B, self.max_node)                      # [B,100,512]
+        pos_i = _SegmentPadFn.apply(bboxes, off, B, self.max_node)               # [B,100,4]
+        h_i = linear_act(_BatchNormFn.apply(h_i, self.bn_gat), self.fc_gat.weight, self.fc_gat.bias, "elu")    # [B,100,480]
+        pos_i = linear_act(_BatchNormFn.apply(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")  # [B,100,32]
+        v = _ConcatColsFn.apply(h_i, pos_i).view(B * self.max_node, 512)          # node rows; no permute needed
+        for i in range(1, 9):
+            v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
+        h_feature = _L2NormMeanFn.apply(v, B)                                     # l2norm over nodes + mean (:201-204)
+        all_feats = _ConcatColsFn.apply(x, h_feature, t)
+        return linear_act(_BatchNormFn.apply(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
+                          None, torch.float32)

@@ -1,0 +1,1 @@
+from .build import build_model  # noqa: F401

@@ -1,0 +1,424 @@
+"""SwinV2 image encoder on libmvuld_hip.so -- same module tree / state_dict keys as the reference's
+``mvuld/models/swin_transformer_v2.py`` (SwinTransformerV2 :503-652), different execution:
+
+* tokens stay ``[B*L, C]`` in image order for the whole network; the cyclic shift, window_partition and
+  window_reverse (:279-299) are an index map inside the fused attention kernel, never a copy;
+* one ``torch.autograd.Function`` per block with a hand-written backward: every GEMM / LayerNorm /
+  attention / reduction is a C-ABI kernel, residual-gradient joins ride GEMM epilogues;
+* the ``[nW*B, H, N, N]`` score tensor, the gathered relative-position bias ``[H, N, N]`` and the shift
+  mask ``[nW, N, N]`` are never materialised (bias comes from the ``(2w-1)^2 x H`` table, the mask from the
+  3x3 region ids of :248-264).
+
+Public surface kept: ``SwinTransformerV2(img_size, patch_size, in_chans, num_classes, embed_dim, depths,
+num_heads, window_size, mlp_ratio, qkv_bias, drop_rate, attn_drop_rate, drop_path_rate, ape, patch_norm,
+use_checkpoint, pretrained_window_sizes)`` with ``forward_features``, ``forward``, ``no_weight_decay``,
+``no_weight_decay_keywords``, ``flops``, ``output_num``.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from ..hip import call, ptr, dt
+
+LN_EPS = 1e-5
+
+
+def _coords_table(ws, pretrained_ws):
+    """log-spaced relative coordinate table [(2ws-1)^2, 2] (reference :97-113)."""
+    r = torch.arange(-(ws - 1), ws, dtype=torch.float32)
+    t = torch.stack(torch.meshgrid(r, r, indexing="ij"), dim=-1)
+    t = t / ((pretrained_ws - 1) if pretrained_ws > 0 else (ws - 1)) * 8
+    t = torch.sign(t) * torch.log2(torch.abs(t) + 1.0) / np.log2(8)
+    return t.reshape(1, 2 * ws - 1, 2 * ws - 1, 2).contiguous()
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+
+
+# ------------------------------------------------------------------------------------------------ functions
+class _PatchEmbedFn(torch.autograd.Function):
+    """4x4/4 conv as im2col + GEMM, then LayerNorm (reference PatchEmbed.forward :485-493)."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, g, beta, act_dtype):
+        hip.require_gpu(img)
+        B, Cin, S, _ = img.shape
+        assert Cin == 3 and w.shape[1:] == (3, 4, 4), "patch embed kernel covers in_chans=3, patch_size=4"
+        E = w.shape[0]
+        T = B * (S // 4) ** 2
+        cols = torch.empty((T, 48), dtype=act_dtype, device=img.device)
+        img = img.contiguous()
+        call("im2col_patch4", ptr(img), ptr(cols), B, S, dt(cols))
+        y = ops.gemm_nt(cols, ops.weight(w, act_dtype).view(E, 48), bias=b.data)
+        out, mean, rstd, _ = ops.layernorm_fwd(y, g.data, beta.data, LN_EPS)
+        ctx.save_for_backward(cols, y, mean, rstd)
+        ctx.params = (w, b, g, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cols, y, mean, rstd = ctx.saved_tensors
+        w, b, g, beta = ctx.params
+        dy = ops.layernorm_bwd(dout.contiguous(), y, g, beta, mean, rstd)
+        ops.linear_wgrad(dy, cols, w, b)
+        return None, None, None, None, None, None
+
+
+class _SwinBlockFn(torch.autograd.Function):
+    """SwinTransformerBlock.forward (:270-306) incl. WindowAttention (:140-179) and Mlp (:26-32)."""
+
+    @staticmethod
+    def forward(ctx, x, blk, rowscale):
+        a = blk.attn
+        B, res, C, H = blk._batch, blk.input_resolution[0], blk.dim, blk.num_heads
+        ws, shift = blk.window_size, blk.shift_size
+        L = res * res
+        ad = x.dtype
+        # qkv bias = (q_bias, 0, v_bias)   (:147-150)
+        qb = blk._qkv_bias_buf(x.device)
+        qkv = ops.gemm_nt(x, ops.weight(a.qkv.weight, ad), bias=qb)
+        T2 = (2 * ws - 1) ** 2
+        hidden = torch.empty((T2, 512), dtype=torch.float32, device=x.device)
+        table16 = torch.empty((T2, H), dtype=torch.float32, device=x.device)
+        coords = a.relative_coords_table
+        call("cpb_table_fwd", ptr(coords), ptr(a.cpb_mlp[0].weight), ptr(a.cpb_mlp[0].bias), ptr(a.cpb_mlp[2].weight),
+             ptr(hidden), ptr(table16), T2, H)
+        ls = a.logit_scale.data.view(-1)
+        geom = ops.AttnGeom(0, B, H, C // H, ws * ws, (res // ws) ** 2, res, ws, shift)
+        att, lse = ops.attn_fwd(geom, qkv, table16, ls)
+        proj = ops.gemm_nt(att, ops.weight(a.proj.weight, ad), bias=a.proj.bias.data)
+        x1, mean1, rstd1, _ = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x,
+                                                rowscale=rowscale, rows_per_sample=L)
+        hpre = torch.empty((x.shape[0], blk.mlp.fc1.weight.shape[0]), dtype=ad, device=x.device)
+        hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre)
+        m = ops.gemm_nt(hact, ops.weight(blk.mlp.fc2.weight, ad), bias=blk.mlp.fc2.bias.data)
+        x2, mean2, rstd2, _ = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1,
+                                                rowscale=rowscale, rows_per_sample=L)
+        ctx.save_for_backward(x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale)
+        ctx.blk, ctx.geom = blk, geom
+        return x2
+
+    @staticmethod
+    def backward(ctx, g):
+        x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale = ctx.saved_tensors
+        blk, geom = ctx.blk, ctx.geom
+        a = blk.attn
+        ad = x.dtype
+        L = blk.input_resolution[0] ** 2
+        C, H = blk.dim, blk.num_heads
+        g = g.contiguous()
+        # ---- FFN branch: x2 = x1 + rs * LN(m)
+        dm = ops.layernorm_bwd(g, m, blk.norm2.weight, blk.norm2.bias, mean2, rstd2, rowscale, L)
+        ops.linear_wgrad(dm, hact, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        dhpre = ops.gemm_nt(dm, ops.weight_t(blk.mlp.fc2.weight, ad), epi=hip.EPI_MUL_DGELU, aux=hpre)
+        ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        g1 = ops.gemm_nt(dhpre, ops.weight_t(blk.mlp.fc1.weight, ad), epi=hip.EPI_ADD_AUX, aux=g)
+        # ---- attention branch: x1 = x + rs * LN(proj)
+        dproj = ops.layernorm_bwd(g1, proj, blk.norm1.weight, blk.norm1.bias, mean1, rstd1, rowscale, L)
+        ops.linear_wgrad(dproj, att, a.proj.weight, a.proj.bias)
+        datt = ops.gemm_nt(dproj, ops.weight_t(a.proj.weight, ad))
+        T2 = table16.shape[0]
+        dtable = torch.zeros((T2, H), dtype=torch.float32, device=x.device)
+        dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
+                            ops.grad_of(a.logit_scale).view(-1))
+        call("cpb_table_bwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[2].weight), ptr(hidden), ptr(table16), ptr(dtable),
+             ptr(ops.grad_of(a.cpb_mlp[0].weight)), ptr(ops.grad_of(a.cpb_mlp[0].bias)), ptr(ops.grad_of(a.cpb_mlp[2].weight)), T2, H)
+        ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
+        if a.q_bias is not None:
+            ops.colsum_into(dqkv, ops.grad_of(a.q_bias), N=C, col0=0)
+            ops.colsum_into(dqkv, ops.grad_of(a.v_bias), N=C, col0=2 * C)
+        dx = ops.gemm_nt(dqkv, ops.weight_t(a.qkv.weight, ad), epi=hip.EPI_ADD_AUX, aux=g1)
+        return dx, None, None
+
+
+class _PatchMergeFn(torch.autograd.Function):
+    """PatchMerging.forward (:343-364): 2x2 gather-concat -> Linear(4C->2C, no bias) -> LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, pm, B):
+        res, C = pm.input_resolution[0], pm.dim
+        ad = x.dtype
+        xg = torch.empty((B * (res // 2) ** 2, 4 * C), dtype=ad, device=x.device)
+        call("patch_merge_gather", ptr(x), ptr(xg), B, res, C, 0, dt(x))
+        y = ops.gemm_nt(xg, ops.weight(pm.reduction.weight, ad))
+        out, mean, rstd, _ = ops.layernorm_fwd(y, pm.norm.weight.data, pm.norm.bias.data, LN_EPS)
+        ctx.save_for_backward(xg, y, mean, rstd)
+        ctx.pm, ctx.B = pm, B
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xg, y, mean, rstd = ctx.saved_tensors
+        pm, B = ctx.pm, ctx.B
+        res, C = pm.input_resolution[0], pm.dim
+        ad = xg.dtype
+        dy = ops.layernorm_bwd(dout.contiguous(), y, pm.norm.weight, pm.norm.bias, mean, rstd)
+        ops.linear_wgrad(dy, xg, pm.reduction.weight, None)
+        dxg = ops.gemm_nt(dy, ops.weight_t(pm.reduction.weight, ad))
+        dx = torch.empty((B * res * res, C), dtype=ad, device=xg.device)
+        call("patch_merge_gather", ptr(dxg), ptr(dx), B, res, C, 1, dt(dx))
+        return dx, None, None
+
+
+class _NormPoolFn(torch.autograd.Function):
+    """final LayerNorm + AdaptiveAvgPool1d(1) + flatten (:632-634)."""
+
+    @staticmethod
+    def forward(ctx, x, norm, B):
+        L, C = x.shape[0] // B, x.shape[1]
+        y, mean, rstd, _ = ops.layernorm_fwd(x, norm.weight.data, norm.bias.data, LN_EPS)
+        out = torch.empty((B, C), dtype=x.dtype, device=x.device)
+        call("mean_pool_fwd", ptr(y), None, ptr(out), B, L, C, dt(x))
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.norm, ctx.B = norm, B
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd = ctx.saved_tensors
+        norm, B = ctx.norm, ctx.B
+        L, C = x.shape[0] // B, x.shape[1]
+        dy = torch.empty_like(x)
+        dout = dout.contiguous()
+        call("mean_pool_bwd", ptr(dout), None, ptr(dy), B, L, C, dt(x))
+        dx = ops.layernorm_bwd(dy, x, norm.weight, norm.bias, mean, rstd)
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------ modules
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        assert drop == 0.0, "MODEL.DROP_RATE > 0 is not used by the hot-path configs"
+
+
+class WindowAttention(nn.Module):
+    """Parameter container of the reference WindowAttention (:67-138); arithmetic lives in _SwinBlockFn."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, attn_drop=0., proj_drop=0., pretrained_window_size=(0, 0)):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.pretrained_window_size = tuple(pretrained_window_size)
+        assert attn_drop == 0.0 and proj_drop == 0.0
+        assert dim // num_heads in (32, 64), "fused window attention supports head_dim 32 or 64"
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1))), requires_grad=True)
+        self.cpb_mlp = nn.Sequential(nn.Linear(2, 512, bias=True), nn.ReLU(inplace=True), nn.Linear(512, num_heads, bias=False))
+        self.register_buffer("relative_coords_table", _coords_table(self.window_size[0], self.pretrained_window_size[0]))
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.q_bias = None
+            self.v_bias = None
+        self.proj = nn.Linear(dim, dim)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # geometry buffers of reference checkpoints that this implementation computes analytically
+        state_dict.pop(prefix + "relative_position_index", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def flops(self, N):
+        return N * self.dim * 3 * self.dim + 2 * self.num_heads * N * (self.dim // self.num_heads) * N + N * self.dim * self.dim
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, drop=0.,
+                 attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, pretrained_window_size=0):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
+        self.window_size, self.shift_size, self.mlp_ratio = window_size, shift_size, mlp_ratio
+        if min(self.input_resolution) <= self.window_size:       # reference :228-231
+            self.shift_size = 0
+            self.window_size = min(self.input_resolution)
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        assert self.input_resolution[0] == self.input_resolution[1] and self.input_resolution[0] % self.window_size == 0
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, (self.window_size, self.window_size), num_heads, qkv_bias, attn_drop, drop,
+                                    (pretrained_window_size, pretrained_window_size))
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), drop=drop)
+        self._batch = 0
+        self._qb = None
+
+    def _qkv_bias_buf(self, device):
+        a = self.attn
+        if a.q_bias is None:
+            return None
+        C = self.dim
+        if self._qb is None or self._qb.device != device:
+            self._qb = torch.zeros(3 * C, dtype=torch.float32, device=device)
+        self._qb[:C].copy_(a.q_bias.data)
+        self._qb[2 * C:].copy_(a.v_bias.data)
+        return self._qb
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "attn_mask", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x, B, rowscale=None):
+        self._batch = B
+        return _SwinBlockFn.apply(x, self, rowscale)
+
+    def flops(self):
+        H, W = self.input_resolution
+        nW = H * W / self.window_size / self.window_size
+        return 2 * self.dim * H * W + nW * self.attn.flops(self.window_size * self.window_size) + \
+            2 * H * W * self.dim * self.dim * self.mlp_ratio
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, input_resolution, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution, self.dim = tuple(input_resolution), dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(2 * dim)
+
+    def forward(self, x, B):
+        H, W = self.input_resolution
+        assert x.shape[0] == B * H * W, "input feature has wrong size"
+        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
+        return _PatchMergeFn.apply(x, self, B)
+
+    def flops(self):
+        H, W = self.input_resolution
+        return (H // 2) * (W // 2) * 4 * self.dim * 2 * self.dim + H * W * self.dim // 2
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=True, drop=0., attn_drop=0.,
+                 drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False, pretrained_window_size=0):
+        super().__init__()
+        self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads, window_size=window_size,
+                                 shift_size=0 if (i % 2 == 0) else window_size // 2, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                 drop=drop, attn_drop=attn_drop,
+                                 drop_path=drop_path[i] if isinstance(drop_path, (list, tuple)) else drop_path,
+                                 pretrained_window_size=pretrained_window_size)
+            for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim=dim) if downsample is not None else None
+
+    def _init_respostnorm(self):
+        for blk in self.blocks:
+            for n in (blk.norm1, blk.norm2):
+                nn.init.constant_(n.bias, 0)
+                nn.init.constant_(n.weight, 0)
+
+    def flops(self):
+        f = sum(b.flops() for b in self.blocks)
+        return f + (self.downsample.flops() if self.downsample is not None else 0)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.patches_resolution = [self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]]
+        self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.norm = nn.LayerNorm(embed_dim) if norm_layer is not None else None
+        assert self.norm is not None, "hot-path configs use patch_norm=True"
+
+    def flops(self):
+        Ho, Wo = self.patches_resolution
+        return Ho * Wo * self.embed_dim * self.in_chans * self.patch_size[0] * self.patch_size[1] + Ho * Wo * self.embed_dim
+
+
+class SwinTransformerV2(nn.Module):
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True, use_checkpoint=False,
+                 pretrained_window_sizes=(0, 0, 0, 0), act_dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        assert not ape, "absolute position embedding is not used by the hot-path configs"
+        self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
+        self.ape, self.patch_norm, self.mlp_ratio = ape, patch_norm, mlp_ratio
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.act_dtype = act_dtype
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, norm_layer if patch_norm else None)
+        pr = self.patch_embed.patches_resolution
+        self.patches_resolution = pr
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), input_resolution=(pr[0] // (2 ** i), pr[1] // (2 ** i)), depth=depths[i],
+                num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                attn_drop=attn_drop_rate, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                downsample=PatchMerging if (i < self.num_layers - 1) else None, use_checkpoint=use_checkpoint,
+                pretrained_window_size=pretrained_window_sizes[i]))
+        self.norm = nn.LayerNorm(self.num_features)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        for bly in self.layers:
+            bly._init_respostnorm()
+        self._dp_gen = torch.Generator().manual_seed(0)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"cpb_mlp", "logit_scale", 'relative_position_bias_table'}
+
+    def _droppath_scales(self, B, device):
+        """[n_blocks, B] per-sample keep/(1-p) factors (timm DropPath semantics), one H2D copy per forward."""
+        rates = [blk.drop_path_rate for layer in self.layers for blk in layer.blocks]
+        if not self.training or max(rates) <= 0.0:
+            return None
+        r = torch.tensor(rates).view(-1, 1)
+        keep = (torch.rand(len(rates), B, generator=self._dp_gen) >= r).float() / (1.0 - r)
+        return keep.to(device, non_blocking=True)
+
+    def forward_features(self, x):
+        hip.require_gpu(x)
+        B = x.shape[0]
+        assert x.shape[2] == self.patch_embed.img_size[0] and x.shape[3] == self.patch_embed.img_size[1], \
+            f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.patch_embed.img_size})."
+        pe = self.patch_embed
+        t = _PatchEmbedFn.apply(x.float(), pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, self.act_dtype)
+        scales = self._droppath_scales(B, x.device)
+        k = 0
+        for layer in self.layers:
+            for blk in layer.blocks:
+                rs = scales[k] if (scales is not None and blk.drop_path_rate > 0) else None
+                t = blk(t, B, rs)
+                k += 1
+            if layer.downsample is not None:
+                t = layer.downsample(t, B)
+        return _NormPoolFn.apply(t, self.norm, B)
+
+    def output_num(self):
+        return self.num_features
+
+    def forward(self, x):
+        from .GraphModel import linear_act
+        f = self.forward_features(x)
+        return linear_act(f, self.head.weight, self.head.bias, act=None, out_dtype=torch.float32)
+
+    def flops(self):
+        f = self.patch_embed.flops() + sum(layer.flops() for layer in self.layers)
+        f += self.num_features * self.patches_resolution[0] * self.patches_resolution[1] // (2 ** self.num_layers)
+        return f + self.num_features * self.num_classes

@@ -1,0 +1,320 @@
+"""UniXcoder text encoder on libmvuld_hip.so.
+
+Mirrors the reference surface of ``mvuld/models/unixcoder.py``: ``MyUniXcoder(encoder, config, tokenizer,
+tokenize)`` with ``get_xcode_vec`` (:33-38), ``forward`` (:40-54), ``get_repr`` (:91-95), ``myEncode`` (:56-68) and
+``UniXcoder(model_name)`` with ``.model/.config/.tokenizer/.tokenize`` (:97-152) -- but the encoder is this
+file's own RoBERTa-shaped module (state_dict keys of HF ``RobertaModel``: ``embeddings.*``,
+``encoder.layer.N.attention.self.{query,key,value}``, ``attention.output``, ``intermediate``, ``output``,
+``pooler``) executed by hand-written kernels:
+
+* q/k/v projections are one fused ``[3H, H]`` GEMM (the three weights are stored adjacently; the
+  state_dict still exposes ``query/key/value`` separately);
+* attention is the fused pad-masked kernel: the reference's 3-D mask ``mask[:,None,:]*mask[:,:,None]``
+  (:35-36; additive -10000 in transformers 4.18) is evaluated from the ``valid`` vector, no ``[B,L,L]`` tensor;
+* post-LN blocks are LayerNorm(dense + input) in one kernel; GELU(erf) rides the GEMM epilogue.
+
+Generation (``generate`` / ``Beam``, :176-342) is not on MVulD's path and is not provided.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from ..hip import call, ptr, dt
+
+
+class RobertaConfigLite:
+    """The fields of transformers.RobertaConfig this path reads (defaults: microsoft/unixcoder-base-nine shape)."""
+
+    def __init__(self, vocab_size=51416, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=1026, type_vocab_size=10, pad_token_id=1,
+                 layer_norm_eps=1e-5, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **kw):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size, self.pad_token_id, self.layer_norm_eps = type_vocab_size, pad_token_id, layer_norm_eps
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
+        self.is_decoder = True            # set by the reference (unixcoder.py:109); no effect on a 3-D mask
+        self.eos_token_id = 2
+
+
+# ------------------------------------------------------------------------------------------------ functions
+class _EmbedFn(torch.autograd.Function):
+    """word + position + token-type(0) embeddings, LayerNorm (HF RobertaEmbeddings)."""
+
+    @staticmethod
+    def forward(ctx, word_w, ids, emb, act_dtype):
+        hip.require_gpu(ids)
+        B, L = ids.shape
+        cfg = emb.config
+        H = cfg.hidden_size
+        ids = ids.contiguous()
+        pos = torch.empty((B, L), dtype=torch.int32, device=ids.device)
+        valid = torch.empty((B, L), dtype=torch.int32, device=ids.device)
+        call("position_ids", ptr(ids), ptr(pos), ptr(valid), B, L, cfg.pad_token_id)
+        raw = torch.empty((B * L, H), dtype=act_dtype, device=ids.device)
+        call("embed_fwd", ptr(ids), ptr(pos), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
+             ptr(emb.token_type_embeddings.weight), ptr(raw), B * L, H, cfg.vocab_size, cfg.max_position_embeddings, dt(raw))
+        y, mean, rstd, _ = ops.layernorm_fwd(raw, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data, cfg.layer_norm_eps)
+        ctx.save_for_backward(ids, pos, raw, mean, rstd)
+        ctx.emb = emb
+        ctx.mark_non_differentiable(valid)
+        return y, valid
+
+    @staticmethod
+    def backward(ctx, dy, _dvalid):
+        ids, pos, raw, mean, rstd = ctx.saved_tensors
+        emb = ctx.emb
+        cfg = emb.config
+        H = cfg.hidden_size
+        draw = ops.layernorm_bwd(dy.contiguous(), raw, emb.LayerNorm.weight, emb.LayerNorm.bias, mean, rstd)
+        call("embed_bwd", ptr(ids), ptr(pos), ptr(draw), ptr(ops.grad_of(emb.word_embeddings.weight)),
+             ptr(ops.grad_of(emb.position_embeddings.weight)), ids.numel(), H, cfg.vocab_size, cfg.max_position_embeddings, dt(draw))
+        ops.colsum_into(draw, ops.grad_of(emb.token_type_embeddings.weight)[0])
+        return None, None, None, None
+
+
+class _LayerFn(torch.autograd.Function):
+    """One post-LN transformer block (HF RobertaLayer): fused QKV -> pad-masked attention -> dense ->
+    LN(. + x) -> dense+GELU -> dense -> LN(. + x1)."""
+
+    @staticmethod
+    def forward(ctx, x, valid, layer, B, L):
+        cfg = layer.config
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        ad = x.dtype
+        sa = layer.attention.self
+        qkv = ops.gemm_nt(x, ops.weight(sa.qkv_weight, ad), bias=sa.qkv_bias.data)
+        geom = ops.AttnGeom(1, B, nh, H // nh, L, 1, 0, 0, 0, 1.0 / math.sqrt(H // nh))
+        cx, lse = ops.attn_fwd(geom, qkv, valid=valid)
+        ao = layer.attention.output
+        a = ops.gemm_nt(cx, ops.weight(ao.dense.weight, ad), bias=ao.dense.bias.data)
+        x1, mean1, rstd1, s1 = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps,
+                                                 pre=x, want_sum=True)
+        it, ot = layer.intermediate, layer.output
+        ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device)
+        iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
+        o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
+        x2, mean2, rstd2, s2 = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps,
+                                                 pre=x1, want_sum=True)
+        ctx.save_for_backward(x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2)
+        ctx.layer, ctx.geom = layer, geom
+        return x2
+
+    @staticmethod
+    def backward(ctx, g):
+        x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2 = ctx.saved_tensors
+        layer, geom = ctx.layer, ctx.geom
+        ad = x.dtype
+        sa, ao, it, ot = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        ds2 = ops.layernorm_bwd(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2)
+        ops.linear_wgrad(ds2, iact, ot.dense.weight, ot.dense.bias)
+        dipre = ops.gemm_nt(ds2, ops.weight_t(ot.dense.weight, ad), epi=hip.EPI_MUL_DGELU, aux=ipre)
+        ops.linear_wgrad(dipre, x1, it.dense.weight, it.dense.bias)
+        g1 = ops.gemm_nt(dipre, ops.weight_t(it.dense.weight, ad), epi=hip.EPI_ADD_AUX, aux=ds2)
+        ds1 = ops.layernorm_bwd(g1, s1, ao.LayerNorm.weight, ao.LayerNorm.bias, mean1, rstd1)
+        ops.linear_wgrad(ds1, cx, ao.dense.weight, ao.dense.bias)
+        dcx = ops.gemm_nt(ds1, ops.weight_t(ao.dense.weight, ad))
+        dqkv = ops.attn_bwd(geom, qkv, cx, dcx, lse, valid=valid)
+        ops.linear_wgrad(dqkv, x, sa.qkv_weight, sa.qkv_bias)
+        dx = ops.gemm_nt(dqkv, ops.weight_t(sa.qkv_weight, ad), epi=hip.EPI_ADD_AUX, aux=ds1)
+        return dx, None, None, None, None
+
+
+class _MaskedMeanFn(torch.autograd.Function):
+    """(tok * mask).sum(1) / mask.sum(-1)   (unixcoder.py:37)."""
+
+    @staticmethod
+    def forward(ctx, tok, valid, B, L):
+        H = tok.shape[1]
+        out = torch.empty((B, H), dtype=tok.dtype, device=tok.device)
+        call("mean_pool_fwd", ptr(tok), ptr(valid), ptr(out), B, L, H, dt(tok))
+        ctx.save_for_backward(valid)
+        ctx.dims = (B, L, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (valid,) = ctx.saved_tensors
+        B, L, H = ctx.dims
+        dx = torch.empty((B * L, H), dtype=dout.dtype, device=dout.device)
+        dout = dout.contiguous()
+        call("mean_pool_bwd", ptr(dout), ptr(valid), ptr(dx), B, L, H, dt(dx))
+        return dx, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ modules
+class RobertaSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        self.qkv_weight = nn.Parameter(torch.empty(3 * H, H).normal_(0, 0.02))
+        self.qkv_bias = nn.Parameter(torch.zeros(3 * H))
+        self._register_state_dict_hook(self._split_hook)
+        self._register_load_state_dict_pre_hook(self._merge_hook)
+
+    @staticmethod
+    def _split_hook(module, state_dict, prefix, local_metadata):
+        w = state_dict.pop(prefix + "qkv_weight")
+        b = state_dict.pop(prefix + "qkv_bias")
+        H = w.shape[1]
+        for i, n in enumerate(("query", "key", "value")):
+            state_dict[f"{prefix}{n}.weight"] = w[i * H:(i + 1) * H]
+            state_dict[f"{prefix}{n}.bias"] = b[i * H:(i + 1) * H]
+
+    def _merge_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        names = ("query", "key", "value")
+        if all(f"{prefix}{n}.weight" in state_dict for n in names):
+            state_dict[prefix + "qkv_weight"] = torch.cat([state_dict.pop(f"{prefix}{n}.weight") for n in names], 0)
+            state_dict[prefix + "qkv_bias"] = torch.cat([state_dict.pop(f"{prefix}{n}.bias") for n in names], 0)
+
+
+class _DenseLN(nn.Module):
+    def __init__(self, fin, fout, eps):
+        super().__init__()
+        self.dense = nn.Linear(fin, fout)
+        self.LayerNorm = nn.LayerNorm(fout, eps=eps)
+
+
+class _Dense(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.dense = nn.Linear(fin, fout)
+
+
+class _Attention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = RobertaSelfAttention(config)
+        self.output = _DenseLN(config.hidden_size, config.hidden_size, config.layer_norm_eps)
+
+
+class RobertaLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.attention = _Attention(config)
+        self.intermediate = _Dense(config.hidden_size, config.intermediate_size)
+        self.output = _DenseLN(config.intermediate_size, config.hidden_size, config.layer_norm_eps)
+
+
+class RobertaEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size, padding_idx=config.pad_token_id)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "position_ids", None)          # HF <= 4.30 buffer
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([RobertaLayer(config) for _ in range(config.num_hidden_layers)])
+
+
+class RobertaModel(nn.Module):
+    """RoBERTa encoder with HF state_dict naming; ``forward(ids) -> (tokens [B,L,H],)`` with the reference's
+    pad mask derived from ``ids != pad``."""
+
+    def __init__(self, config, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = config
+        self.act_dtype = act_dtype
+        self.embeddings = RobertaEmbeddings(config)
+        self.encoder = _Encoder(config)
+        self.pooler = _Dense(config.hidden_size, config.hidden_size)       # unused by MVulD; kept for checkpoints
+        for p in self.pooler.parameters():
+            p.requires_grad_(False)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.02)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Embedding):
+                m.weight.data.normal_(0, 0.02)
+
+    def encode(self, source_ids):
+        """-> (tokens [B*L, H], valid int32 [B, L])"""
+        B, L = source_ids.shape
+        x, valid = _EmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, self.embeddings, self.act_dtype)
+        for layer in self.encoder.layer:
+            x = _LayerFn.apply(x, valid, layer, B, L)
+        return x, valid
+
+    def forward(self, source_ids, attention_mask=None):
+        B, L = source_ids.shape
+        x, _ = self.encode(source_ids)
+        return (x.view(B, L, -1),)
+
+
+class MyUniXcoder(nn.Module):
+    def __init__(self, encoder, config, tokenizer=None, tokenize=None):
+        super().__init__()
+        self.encoder = encoder
+        self.config = config
+        self.tokenizer = tokenizer
+        self.tokenize = tokenize
+        self.classifier = nn.Linear(config.hidden_size, 2)
+        self.max_source_length = 512
+
+    def get_xcode_vec(self, source_ids):
+        """Token embeddings [B,L,H] and sentence embeddings [B,H] (masked mean over non-pad tokens)."""
+        B, L = source_ids.shape
+        tok, valid = self.encoder.encode(source_ids)
+        sent = _MaskedMeanFn.apply(tok, valid, B, L)
+        return tok.view(B, L, -1), sent
+
+    def forward(self, source_ids=None, labels=None):
+        from .GraphModel import linear_act, cross_entropy
+        source_ids = source_ids.view(-1, self.max_source_length)
+        _, vec = self.get_xcode_vec(source_ids)
+        logits = linear_act(vec, self.classifier.weight, self.classifier.bias, act=None, out_dtype=torch.float32)
+        if labels is not None:
+            loss, prob = cross_entropy(logits, labels)
+            return loss, prob
+        _, prob = cross_entropy(logits, torch.zeros(logits.shape[0], dtype=torch.int64, device=logits.device))
+        return prob
+
+    def get_repr(self, input_ids, labels=None):
+        source_ids = input_ids.view(-1, self.max_source_length)
+        _, vec = self.get_xcode_vec(source_ids)
+        return vec, labels
+
+    def myEncode(self, sents: list):
+        if self.tokenize is None:
+            raise RuntimeError("myEncode needs the UniXcoder tokenizer (not available offline); pass token ids to get_repr")
+        rows = [self.tokenize([' '.join(s.split())], max_length=512, padding=True)[0] for s in sents]
+        ids = torch.tensor(rows, dtype=torch.long, device=next(self.parameters()).device)
+        vec, _ = self.get_repr(ids)
+        return vec
+
+
+class UniXcoder(nn.Module):
+    """``UniXcoder(model_name)``: builds the encoder from a local config.  ``model_name`` may be a
+    RobertaConfigLite, a dict of its fields, or a hub name (then the unixcoder-base-nine shape is assumed: there
+    is no network, so weights are random-init and no tokenizer is attached)."""
+
+    def __init__(self, model_name="microsoft/unixcoder-base-nine", act_dtype=torch.bfloat16):
+        super().__init__()
+        if isinstance(model_name, RobertaConfigLite):
+            self.config = model_name
+        elif isinstance(model_name, dict):
+            self.config = RobertaConfigLite(**model_name)
+        else:
+            self.config = RobertaConfigLite()
+        self.model = RobertaModel(self.config, act_dtype)
+        self.tokenizer = None
+
+    def tokenize(self, inputs, mode="<encoder-only>", max_length=512, padding=False):
+        raise RuntimeError("UniXcoder tokenizer files are not available offline; feed token ids")
+
+    def forward(self, source_ids):
+        B, L = source_ids.shape
+        tok, valid = self.model.encode(source_ids)
+        return tok.view(B, L, -1), _MaskedMeanFn.apply(tok, valid, B, L)

@@ -1,0 +1,216 @@
+"""Thin, allocation-only wrappers over the C ABI (one Python function per kernel family).
+
+PyTorch is used here for device memory (``torch.empty``), views and streams only; every
+arithmetic operation is a ``libmvuld_hip.so`` call.  Tensors are contiguous; activations are
+f32 or bf16, parameters / gradients / statistics fp32.
+"""
+import math
+
+import torch
+
+from . import hip
+from .hip import call, ptr, dt
+
+# ---------------------------------------------------------------------------------------------
+# weight views: bf16 working copies and transposed copies, refreshed when WEIGHT_EPOCH moves
+WEIGHT_EPOCH = [0]
+FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU kernel
+ATTN_IMPL = ["auto"]                 # "auto" | "simple"
+
+
+def bump_weight_epoch():
+    WEIGHT_EPOCH[0] += 1
+
+
+def weight(p: torch.Tensor, dtype) -> torch.Tensor:
+    """Parameter as a GEMM operand of activation dtype `dtype` ([out, in], row-major)."""
+    if dtype == torch.float32:
+        return p.data if isinstance(p, torch.nn.Parameter) else p
+    if getattr(p, "_mv_w16_store", False):       # ParamStore view: the AdamW kernel keeps it current
+        return p._mv_w16
+    c = getattr(p, "_mv_w16", None)
+    if c is None or getattr(p, "_mv_w16_epoch", -1) != WEIGHT_EPOCH[0]:
+        if c is None:
+            c = torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
+        call("cast", ptr(p), hip.F32, ptr(c), hip.BF16, p.numel())
+        p._mv_w16 = c
+        p._mv_w16_epoch = WEIGHT_EPOCH[0]
+    return c
+
+
+def weight_t(p: torch.Tensor, dtype) -> torch.Tensor:
+    """Transposed operand [in, out] (for dgrad through the NT GEMM)."""
+    key = "_mv_wt32" if dtype == torch.float32 else "_mv_wt16"
+    c = getattr(p, key, None)
+    if c is None or getattr(p, key + "_epoch", -1) != WEIGHT_EPOCH[0]:
+        w = weight(p, dtype)
+        w2 = w.reshape(w.shape[0], -1)
+        if c is None:
+            c = torch.empty((w2.shape[1], w2.shape[0]), dtype=w.dtype, device=w.device)
+        call("transpose", ptr(w2), ptr(c), w2.shape[0], w2.shape[1], 1, dt(w2))
+        setattr(p, key, c)
+        setattr(p, key + "_epoch", WEIGHT_EPOCH[0])
+    return c
+
+
+def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
+    """fp32 gradient buffer of a parameter (atomic-accumulate target)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data, dtype=torch.float32)
+    return p.grad
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, out_mode=hip.OUT_STORE, splitk=1,
+            out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, batch=1, sa=0, sb=0, sc=0,
+            ldaux=None, saux=0):
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias).  2-D contiguous by default; explicit ld/stride for views."""
+    M = a.shape[-2] if M is None else M
+    K = a.shape[-1] if K is None else K
+    N = b.shape[-2] if N is None else N
+    lda = a.stride(-2) if lda is None else lda
+    ldb = b.stride(-2) if ldb is None else ldb
+    if out is None:
+        od = out_dtype or a.dtype
+        shape = (M, N) if batch == 1 else (batch, M, N)
+        out = torch.empty(shape, dtype=od, device=a.device)
+        if batch > 1 and sc == 0:
+            sc = M * N
+    ldc = out.stride(-2) if ldc is None else ldc
+    if aux is not None and ldaux is None:
+        ldaux = aux.stride(-2)
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("gemm_nt: bias must be fp32")
+    call("gemm_nt", ptr(a), lda, sa, ptr(b), ldb, sb, ptr(out), ldc, sc, M, N, K, batch, ptr(bias), epi, ptr(aux),
+         ldaux or 0, saux, float(alpha), out_mode, splitk, dt(a), dt(out), 1 if FORCE_SIMPLE_GEMM[0] else 0)
+    return out
+
+
+def transpose(x, R=None, C=None, batch=1, out=None):
+    R = x.shape[-2] if R is None else R
+    C = x.shape[-1] if C is None else C
+    if out is None:
+        out = torch.empty((C, R) if batch == 1 else (batch, C, R), dtype=x.dtype, device=x.device)
+    call("transpose", ptr(x), ptr(out), R, C, batch, dt(x))
+    return out
+
+
+def colsum_into(x, out, M=None, N=None, ld=None, col0=0):
+    """out[0:N] += column sums of x[:, col0:col0+N]."""
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    ld = x.stride(0) if ld is None else ld
+    call("colsum", x.data_ptr() + col0 * x.element_size(), ld, ptr(out), M, N, dt(x))
+
+
+def wgrad_splitk(n_out, k_out, depth):
+    tiles = math.ceil(n_out / 128) * math.ceil(k_out / 128)
+    ktiles = max(1, depth // 64)
+    want = max(1, 768 // tiles)
+    return int(max(1, min(want, ktiles // 4 if ktiles >= 8 else 1)))
+
+
+def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if b_param is not None:
+        colsum_into(dy, grad_of(b_param))
+    if w_param is None:
+        return
+    dyT = transpose(dy) if dyT is None else dyT
+    xT = transpose(x) if xT is None else xT
+    gw = grad_of(w_param)
+    gemm_nt(dyT, xT, out=gw.view(N, K), out_mode=hip.OUT_ATOMIC, splitk=wgrad_splitk(N, K, M))
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_per_sample=1, pre=None, want_sum=False):
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    xsum = torch.empty_like(x) if (pre is not None and want_sum) else None
+    call("layernorm_fwd", ptr(x), ptr(pre), ptr(xsum), ptr(gamma), ptr(beta), ptr(residual), ptr(rowscale), rows_per_sample,
+         ptr(y), ptr(mean), ptr(rstd), rows, C, eps, dt(x))
+    return y, mean, rstd, xsum
+
+
+def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sample=1):
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    call("layernorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(rowscale), rows_per_sample, ptr(dx),
+         ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)), rows, C, dt(x))
+    return dx
+
+
+def batchnorm_fwd(x, gamma, beta, run_mean, run_var, O, C, I, so, sc, si, training, eps=1e-5, momentum=0.1):
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    sr = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("batchnorm_fwd", ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_var), ptr(sm), ptr(sr), O, C, I, so, sc, si,
+         eps, momentum, 1 if training else 0, dt(x))
+    return y, sm, sr
+
+
+def batchnorm_bwd(dy, x, gamma_p, beta_p, sm, sr, O, C, I, so, sc, si, training):
+    dx = torch.empty_like(x)
+    call("batchnorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(sm), ptr(sr), ptr(dx), ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)),
+         O, C, I, so, sc, si, 1 if training else 0, dt(x))
+    return dx
+
+
+def act_bwd(dy, ref, mode):
+    dx = torch.empty_like(dy)
+    call("act_bwd", ptr(dy), ptr(ref), ptr(dx), dy.numel(), mode, dt(dy))
+    return dx
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("cast", ptr(x), dt(x), ptr(y), hip.F32 if dtype == torch.float32 else hip.BF16, x.numel())
+    return y
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    call("add", ptr(a), ptr(b), ptr(y), a.numel(), dt(a))
+    return y
+
+
+def dropout(x, p, seed):
+    if p <= 0.0:
+        return x
+    y = torch.empty_like(x)
+    call("dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, dt(x))
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+class AttnGeom:
+    """Geometry of one fused-attention call (see include/mvuld_hip.h)."""
+
+    def __init__(self, mode, B, H, hd, N, nW=1, res=0, ws=0, shift=0, scale=1.0):
+        self.mode, self.B, self.H, self.hd, self.N, self.nW = mode, B, H, hd, N, nW
+        self.res, self.ws, self.shift, self.scale = res, ws, shift, scale
+
+    def args(self):
+        return (self.mode, self.B, self.H, self.hd, self.N, self.nW, self.res, self.ws, self.shift, float(self.scale))
+
+
+def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
+    tokens = qkv.shape[0]
+    out = torch.empty((tokens, g.H * g.hd), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((g.B * g.nW * g.H * g.N,), dtype=torch.float32, device=qkv.device)
+    use_mfma = (ATTN_IMPL[0] == "auto" and qkv.dtype == torch.bfloat16 and hasattr(hip.LIB.load(), "mvuld_attn_fwd_mfma"))
+    name = "attn_fwd_mfma" if use_mfma else "attn_fwd_simple"
+    call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
+    return out, lse
+
+
+def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None):
+    dqkv = torch.empty_like(qkv)
+    call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
+         ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), dt(qkv))
+    return dqkv

@@ -1,0 +1,394 @@
+"""GPU parity of individual C-ABI kernels against plain PyTorch fp32 on the CPU (sizes: seconds)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import rel, tol, synth
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def T(name, shape, lo=-1.0, hi=1.0):
+    return synth.tensor("kt/" + name, shape, lo, hi)
+
+
+def dev(x, dtype=None, d="cuda:0"):
+    x = x.to(d)
+    return x.to(dtype) if dtype is not None else x
+
+
+def rt(x, dtype):
+    """round-trip through the storage dtype (so the CPU reference sees the same inputs)."""
+    return x.to(dtype).float()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(70, 50, 36), (256, 384, 128), (300, 200, 72), (129, 131, 64), (64, 2, 1536)])
+def test_gemm_nt_bias_epilogues(gpu, dtype, M, N, K):
+    from mvuld_amd import ops, hip
+    a, b = rt(T("ga", (M, K)), dtype), rt(T("gb", (N, K)), dtype)
+    bias = T("gbias", (N,))
+    ref = a @ b.t() + bias
+    A, B_, Bi = dev(a, dtype), dev(b, dtype), dev(bias)
+    out = ops.gemm_nt(A, B_, bias=Bi)
+    assert rel(out, ref) < tol(dtype)
+    aux = torch.empty((M, N), dtype=dtype, device=gpu)
+    out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=aux)
+    assert rel(aux, ref) < tol(dtype)
+    assert rel(out, F.gelu(ref)) < tol(dtype)
+    out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_ELU)
+    assert rel(out, F.elu(ref)) < tol(dtype)
+    pre = rt(T("gpre", (M, N), -2, 2), dtype)
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_DGELU, aux=dev(pre, dtype))
+    p = pre.clone().requires_grad_(True)
+    F.gelu(p).sum().backward()
+    assert rel(out, (a @ b.t()) * p.grad) < tol(dtype)
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_ADD_AUX, aux=dev(pre, dtype))
+    assert rel(out, a @ b.t() + pre) < tol(dtype)
+    out32 = ops.gemm_nt(A, B_, bias=Bi, out_dtype=torch.float32)
+    assert out32.dtype == torch.float32 and rel(out32, ref) < (2e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_splitk_atomic_and_batched(gpu, dtype):
+    from mvuld_amd import ops, hip
+    M, N, K = 96, 160, 4096
+    a, b = rt(T("sa", (M, K)), dtype), rt(T("sb", (N, K)), dtype)
+    C = torch.ones((M, N), dtype=torch.float32, device=gpu)
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), out=C, out_mode=hip.OUT_ATOMIC, splitk=8)
+    assert rel(C, a @ b.t() + 1.0) < (2e-4 if dtype == torch.float32 else 5e-3)
+    Bn, m, n, k = 5, 100, 100, 512
+    a, b = rt(T("ba", (Bn, m, k)), dtype), rt(T("bb", (Bn, n, k)), dtype)
+    out = ops.gemm_nt(dev(a, dtype).view(Bn * m, k), dev(b, dtype).view(Bn * n, k), M=m, N=n, K=k, lda=k, ldb=k, batch=Bn,
+                      sa=m * k, sb=n * k, alpha=0.01)
+    assert rel(out, 0.01 * a @ b.transpose(1, 2)) < tol(dtype)
+
+
+def test_gemm_mfma_matches_simple(gpu):
+    """A=I with an asymmetric B catches fragment-layout transposes; then random data, both paths."""
+    from mvuld_amd import ops
+    M = N = K = 256
+    eye = torch.eye(M, dtype=torch.bfloat16, device=gpu)
+    b = (torch.arange(N * K, device=gpu).view(N, K) % 251).to(torch.bfloat16)
+    out = ops.gemm_nt(eye, b, out_dtype=torch.float32)
+    assert torch.equal(out, b.float().t().contiguous())
+    a, b2 = dev(T("ma", (384, 320)), torch.bfloat16), dev(T("mb", (200, 320)), torch.bfloat16)
+    fast = ops.gemm_nt(a, b2, out_dtype=torch.float32)
+    ops.FORCE_SIMPLE_GEMM[0] = True
+    try:
+        slow = ops.gemm_nt(a, b2, out_dtype=torch.float32)
+    finally:
+        ops.FORCE_SIMPLE_GEMM[0] = False
+    assert rel(fast, slow) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_colsum(gpu, dtype):
+    from mvuld_amd import ops
+    x = rt(T("tx", (3, 70, 130)), dtype)
+    out = ops.transpose(dev(x, dtype), R=70, C=130, batch=3)
+    assert torch.equal(out.float().cpu(), x.transpose(1, 2).contiguous())
+    y = rt(T("cs", (1000, 96)), dtype)
+    acc = torch.ones(32, device=gpu)
+    ops.colsum_into(dev(y, dtype), acc, N=32, col0=64)
+    assert rel(acc, y[:, 64:].sum(0) + 1) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [32, 128, 768, 1024])
+def test_layernorm_fwd_bwd(gpu, dtype, C):
+    from mvuld_amd import ops
+    rows, rps = 48, 12
+    x, res = rt(T("lx", (rows, C)), dtype), rt(T("lr", (rows, C)), dtype)
+    gm, bt = torch.nn.Parameter(T("lg", (C,), 0.5, 1.5)), torch.nn.Parameter(T("lb", (C,)))
+    rsc = T("lrs", (rows // rps,), 0.0, 2.0)
+    dy = rt(T("ldy", (rows, C)), dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = res + rsc.repeat_interleave(rps)[:, None] * F.layer_norm(xr, (C,), gm, bt, 1e-5)
+    ref.backward(dy)
+    G, Bt = torch.nn.Parameter(dev(gm.data)), torch.nn.Parameter(dev(bt.data))
+    y, mean, rstd, _ = ops.layernorm_fwd(dev(x, dtype), G.data, Bt.data, 1e-5, residual=dev(res, dtype), rowscale=dev(rsc), rows_per_sample=rps)
+    assert rel(y, ref) < tol(dtype)
+    dx = ops.layernorm_bwd(dev(dy, dtype), dev(x, dtype), G, Bt, mean, rstd, dev(rsc), rps)
+    assert rel(dx, xr.grad) < tol(dtype)
+    assert rel(G.grad, gm.grad) < 1e-3 and rel(Bt.grad, bt.grad) < 1e-3
+    # post-LN form: LN(x + pre)
+    y2, _, _, xs = ops.layernorm_fwd(dev(x, dtype), G.data, Bt.data, 1e-5, pre=dev(res, dtype), want_sum=True)
+    assert rel(y2, F.layer_norm(rt(x + res, dtype), (C,), gm, bt, 1e-5)) < tol(dtype)
+    assert rel(xs, x + res) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(8, 96), (6, 100, 20)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm(gpu, dtype, shape, training):
+    from mvuld_amd.models.GraphModel import _BatchNormFn
+    C = shape[1]
+    bn = torch.nn.BatchNorm1d(C)
+    bn.weight.data = T("bw", (C,), 0.5, 1.5); bn.bias.data = T("bb", (C,))
+    bn.running_mean.data = T("brm", (C,), -0.2, 0.2); bn.running_var.data = T("brv", (C,), 0.5, 1.5)
+    bn.train(training)
+    import copy
+    gb = copy.deepcopy(bn).to(gpu)
+    x = rt(T("bx", shape), dtype)
+    dy = rt(T("bdy", shape), dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = bn(xr)
+    ref.backward(dy)
+    xg = dev(x, dtype).requires_grad_(True)
+    y = _BatchNormFn.apply(xg, gb)
+    y.backward(dev(dy, dtype))
+    assert rel(y, ref) < tol(dtype)
+    assert rel(xg.grad, xr.grad) < tol(dtype)
+    assert rel(gb.weight.grad, bn.weight.grad) < 2e-3 and rel(gb.bias.grad, bn.bias.grad) < 2e-3
+    assert rel(gb.running_mean, bn.running_mean) < 1e-4 and rel(gb.running_var, bn.running_var) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _swin_attn_ref(qkv, table16, ls, B, H, hd, res, ws, shift):
+    from oracle import swin_ref
+    C = H * hd
+    x = qkv.view(B, res, res, 3 * C)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    n = res // ws
+    xw = x.view(B, n, ws, n, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(B * n * n, ws * ws, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0], xw[1], xw[2]
+    att = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-1, -2)
+    att = att * torch.clamp(ls, max=math.log(100.0)).exp().view(1, H, 1, 1)
+    N = ws * ws
+    att = att + table16[swin_ref.rel_index(ws).reshape(-1)].view(N, N, H).permute(2, 0, 1)[None]
+    if shift:
+        m = swin_ref.shift_mask(res, ws, shift)
+        att = (att.view(B, n * n, H, N, N) + m[None, :, None]).view(B * n * n, H, N, N)
+    o = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, n, n, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, res, res, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    return o.reshape(B * res * res, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("res,ws,shift,H", [(14, 7, 3, 2), (14, 7, 0, 2), (28, 14, 7, 1), (14, 14, 0, 4)])
+def test_swin_window_attention(gpu, dtype, res, ws, shift, H):
+    from mvuld_amd import ops
+    B, hd = 2, 32
+    C = H * hd
+    qkv = rt(T("aq", (B * res * res, 3 * C), -2, 2), dtype)
+    T2 = (2 * ws - 1) ** 2
+    table = T("at", (T2, H), 0.0, 16.0)
+    ls = T("als", (H,), 1.5, 5.0)          # some heads above the ln(100) clamp
+    dout = rt(T("ado", (B * res * res, C)), dtype)
+    q_, t_, l_ = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    ref = _swin_attn_ref(q_, t_, l_, B, H, hd, res, ws, shift)
+    ref.backward(dout)
+    g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+    ops.ATTN_IMPL[0] = "simple"
+    try:
+        out, lse = ops.attn_fwd(g, dev(qkv, dtype), dev(table), dev(ls))
+    finally:
+        ops.ATTN_IMPL[0] = "auto"
+    assert rel(out, ref) < tol(dtype)
+    dtab = torch.zeros((T2, H), device=gpu)
+    dls = torch.zeros(H, device=gpu)
+    dqkv = ops.attn_bwd(g, dev(qkv, dtype), out, dev(dout, dtype), lse, dev(table), dev(ls), None, dtab, dls)
+    assert rel(dqkv, q_.grad) < tol(dtype) * 2
+    assert rel(dtab, t_.grad) < tol(dtype) * 2
+    assert rel(dls, l_.grad) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [32, 64])
+def test_padmask_attention(gpu, dtype, hd):
+    from mvuld_amd import ops
+    B, L, H = 3, 100, 2
+    C = H * hd
+    lens = [100, 37, 5]
+    valid = torch.zeros(B, L, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        valid[i, :n] = 1
+    qkv = rt(T("pq", (B * L, 3 * C), -2, 2), dtype)
+    dout = rt(T("pdo", (B * L, C)), dtype) * valid.view(-1, 1)
+    q_ = qkv.clone().requires_grad_(True)
+    x = q_.view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    m = valid.bool()
+    add = (1.0 - (m[:, None, :] & m[:, :, None]).float()[:, None]) * -10000.0
+    s = x[0] @ x[1].transpose(-1, -2) / math.sqrt(hd) + add
+    ref = (s.softmax(-1) @ x[2]).transpose(1, 2).reshape(B * L, C)
+    ref.backward(dout)
+    g = ops.AttnGeom(1, B, H, hd, L, 1, 0, 0, 0, 1.0 / math.sqrt(hd))
+    ops.ATTN_IMPL[0] = "simple"
+    try:
+        out, lse = ops.attn_fwd(g, dev(qkv, dtype), valid=dev(valid))
+    finally:
+        ops.ATTN_IMPL[0] = "auto"
+    vm = valid.view(-1, 1).float()
+    assert rel(out.float().cpu() * vm, ref * vm) < tol(dtype)
+    dqkv = ops.attn_bwd(g, dev(qkv, dtype), out, dev(dout, dtype), lse, valid=dev(valid))
+    assert rel(dqkv.float().cpu() * vm, q_.grad * vm) < tol(dtype) * 2
+
+
+def test_cpb_table(gpu):
+    from mvuld_amd import hip
+    from mvuld_amd.hip import call, ptr
+    from oracle import swin_ref
+    ws, H = 7, 4
+    coords = swin_ref.coords_table(ws, 6)
+    T2 = coords.shape[0]
+    W1 = T("c1", (512, 2)).requires_grad_(True); b1 = T("cb", (512,)).requires_grad_(True); W2 = T("c2", (H, 512), -0.2, 0.2).requires_grad_(True)
+    ref = 16 * torch.sigmoid(F.linear(F.relu(F.linear(coords, W1, b1)), W2))
+    dt_ = T("cdt", (T2, H))
+    ref.backward(dt_)
+    hid = torch.empty((T2, 512), device=gpu); tab = torch.empty((T2, H), device=gpu)
+    # keep every device operand alive in a named variable (a temporary's block can be re-used by the next upload)
+    gc, gW1, gb1, gW2, gdt = dev(coords), dev(W1.data), dev(b1.data), dev(W2.data), dev(dt_)
+    call("cpb_table_fwd", ptr(gc), ptr(gW1), ptr(gb1), ptr(gW2), ptr(hid), ptr(tab), T2, H)
+    assert rel(tab, ref) < 1e-5
+    d1, db, d2 = torch.zeros(512, 2, device=gpu), torch.zeros(512, device=gpu), torch.zeros(H, 512, device=gpu)
+    call("cpb_table_bwd", ptr(gc), ptr(gW2), ptr(hid), ptr(tab), ptr(gdt), ptr(d1), ptr(db), ptr(d2), T2, H)
+    assert rel(d1, W1.grad) < 1e-4 and rel(db, b1.grad) < 1e-4 and rel(d2, W2.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ graph
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gatconv(gpu, dtype):
+    from mvuld_amd.models.GraphModel import GATConv
+    from mvuld_amd.graph import BatchedGraph
+    from oracle import head_ref
+    N, Fin, H, O = 37, 64, 4, 96
+    # multigraph: duplicate edges, duplicate self loops, in-degree-1 nodes
+    src = torch.tensor([0, 0, 1, 2, 2, 5, 5, 5, 9, 9] + list(range(N)) + [3, 3], dtype=torch.int64)
+    dst = torch.tensor([1, 1, 2, 3, 3, 6, 6, 7, 9, 9] + list(range(N)) + [3, 3], dtype=torch.int64)
+    g = BatchedGraph(src, dst, [20, 17]).to(gpu)
+    conv = GATConv(Fin, O, H, feat_drop=0.0)
+    sd = {"fc.weight": T("gw", (H * O, Fin), -0.2, 0.2), "attn_l": T("gl", (1, H, O), -0.3, 0.3),
+          "attn_r": T("gr", (1, H, O), -0.3, 0.3), "bias": T("gbb", (H * O,))}
+    conv.load_state_dict(sd)
+    conv = conv.to(gpu)
+    x = rt(T("gx", (N, Fin)), dtype)
+    dy = rt(T("gdy", (N, H, O)), dtype)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    if dtype == torch.bfloat16:
+        sdr["fc.weight"] = rt(sd["fc.weight"], dtype).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ref = head_ref.gat_conv(sdr, "", xr, src, dst, H, O)
+    ref.backward(dy)
+    xg = dev(x, dtype).requires_grad_(True)
+    out = conv(g, xg)
+    out.backward(dev(dy, dtype))
+    assert rel(out, ref) < tol(dtype)
+    assert rel(xg.grad, xr.grad) < tol(dtype) * 2
+    for k, p in (("fc.weight", conv.fc.weight), ("attn_l", conv.attn_l), ("attn_r", conv.attn_r), ("bias", conv.bias)):
+        assert rel(p.grad, sdr[k].grad) < tol(dtype) * 2, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_segment_pad_l2norm_meanpool(gpu, dtype):
+    from mvuld_amd.models.GraphModel import _SegmentPadFn, _L2NormMeanFn
+    from mvuld_amd.models.unixcoder import _MaskedMeanFn
+    from oracle import head_ref
+    bnn = [60, 100, 130, 7]
+    off = torch.tensor([0] + list(torch.tensor(bnn).cumsum(0)), dtype=torch.int32)
+    h = rt(T("sp", (sum(bnn), 24)), dtype)
+    hr = h.clone().requires_grad_(True)
+    ref = head_ref.unbatch_pad(hr, bnn)
+    dy = rt(T("spd", tuple(ref.shape)), dtype)
+    ref.backward(dy)
+    hg = dev(h, dtype).requires_grad_(True)
+    out = _SegmentPadFn.apply(hg, dev(off), len(bnn), 100)
+    out.backward(dev(dy, dtype))
+    assert torch.equal(out.float().cpu(), ref.detach()) and torch.equal(hg.grad.float().cpu(), hr.grad)
+    B, Nn, C = 3, 100, 40
+    g_ = rt(T("l2", (B, Nn, C)), dtype)
+    gr = g_.clone().requires_grad_(True)
+    r = (gr / gr.pow(2).sum(1, keepdim=True).sqrt()).mean(1)
+    d = rt(T("l2d", (B, C)), dtype)
+    r.backward(d)
+    gg = dev(g_, dtype).view(B * Nn, C).requires_grad_(True)
+    o = _L2NormMeanFn.apply(gg, B)
+    o.backward(dev(d, dtype))
+    assert rel(o, r) < tol(dtype) and rel(gg.grad.view(B, Nn, C), gr.grad) < tol(dtype)
+    L = 50
+    valid = torch.zeros(B, L, dtype=torch.int32); valid[0, :50] = 1; valid[1, :13] = 1; valid[2, :1] = 1
+    t_ = rt(T("mp", (B, L, C)), dtype)
+    tr = t_.clone().requires_grad_(True)
+    m = valid.float()
+    r = (tr * m[..., None]).sum(1) / m.sum(-1)[..., None]
+    r.backward(d)
+    tg = dev(t_, dtype).view(B * L, C).requires_grad_(True)
+    o = _MaskedMeanFn.apply(tg, dev(valid), B, L)
+    o.backward(dev(d, dtype))
+    assert rel(o, r) < tol(dtype) and rel(tg.grad.view(B, L, C), tr.grad) < tol(dtype)
+
+
+def test_cross_entropy_adamw_sumsq(gpu):
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.hip import call, ptr
+    lg = T("ce", (9, 2), -3, 3)
+    tg = synth.ints("kt/cet", (9,), 0, 2)
+    lr_ = lg.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr_, tg)
+    ref.backward()
+    lgpu = dev(lg).requires_grad_(True)
+    loss, probs = cross_entropy(lgpu, dev(tg))
+    loss.backward()
+    assert rel(loss, ref) < 1e-5 and rel(probs, lg.softmax(1)) < 1e-5 and rel(lgpu.grad, lr_.grad) < 1e-5
+    n = 10007
+    p0, g0 = T("ap", (n,)), T("ag", (n,))
+    p = torch.nn.Parameter(p0.clone()); p.grad = g0.clone() * 0.5
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.005)
+    P, G = dev(p0.clone()), dev(g0.clone())
+    M_, V_ = torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    P16 = torch.empty(n, dtype=torch.bfloat16, device=gpu)
+    ss = torch.zeros(1, device=gpu); no = torch.zeros(2, device=gpu)
+    call("sumsq", ptr(G), n, ptr(ss))
+    assert rel(ss, (g0 ** 2).sum()) < 1e-5
+    call("clip_coef", ptr(ss), float(g0.norm() * 0.5), ptr(no))
+    for step in (1, 2, 3):
+        opt.step()
+        call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, step, ptr(no))
+    assert rel(no[0], g0.norm()) < 1e-5 and abs(float(no[1]) - 0.5) < 1e-4
+    assert rel(P, p.data) < 1e-5 and rel(P16, p.data) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_im2col_patchmerge_dropout(gpu, dtype):
+    from mvuld_amd.hip import call, ptr, dt
+    B, L, Hd, V, MP = 2, 12, 40, 50, 20
+    ids = synth.ints("kt/ids", (B, L), 2, V); ids[0, 8:] = 1; ids[1, 3:] = 1
+    word, posw, typ = T("ew", (V, Hd)), T("ep", (MP, Hd)), T("et", (3, Hd))
+    pos = torch.empty((B, L), dtype=torch.int32, device=gpu); valid = torch.empty_like(pos)
+    gids, gword, gposw, gtyp = dev(ids), dev(word), dev(posw), dev(typ)
+    call("position_ids", ptr(gids), ptr(pos), ptr(valid), B, L, 1)
+    m = ids.ne(1).long()
+    assert torch.equal(pos.cpu().long(), torch.cumsum(m, 1) * m + 1) and torch.equal(valid.cpu().long(), m)
+    out = torch.empty((B * L, Hd), dtype=dtype, device=gpu)
+    call("embed_fwd", ptr(gids), ptr(pos), ptr(gword), ptr(gposw), ptr(gtyp), ptr(out), B * L, Hd, V, MP, dt(out))
+    ref = word[ids] + posw[pos.cpu().long()] + typ[0]
+    assert rel(out.view(B, L, Hd), ref) < tol(dtype)
+    img = T("im", (2, 3, 16, 16))
+    cols = torch.empty((2 * 16, 48), dtype=dtype, device=gpu)
+    gimg = dev(img)
+    call("im2col_patch4", ptr(gimg), ptr(cols), 2, 16, dt(cols))
+    w = T("imw", (8, 3, 4, 4))
+    ref = F.conv2d(rt(img, dtype), w, stride=4).flatten(2).transpose(1, 2).reshape(32, 8)
+    assert rel(cols.float().cpu() @ w.view(8, 48).t(), ref) < 1e-4
+    x = rt(T("pm", (2, 6, 6, 5)), dtype)
+    y = torch.empty((2 * 9, 20), dtype=dtype, device=gpu)
+    gx = dev(x, dtype)
+    call("patch_merge_gather", ptr(gx), ptr(y), 2, 6, 5, 0, dt(y))
+    ref = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).reshape(18, 20)
+    assert torch.equal(y.float().cpu(), ref)
+    back = torch.empty((2 * 36, 5), dtype=dtype, device=gpu)
+    call("patch_merge_gather", ptr(y), ptr(back), 2, 6, 5, 1, dt(y))
+    assert torch.equal(back.float().cpu().view(2, 6, 6, 5), x)
+    from mvuld_amd import ops
+    big = torch.ones(200000, dtype=dtype, device=gpu)
+    d1, d2 = ops.dropout(big, 0.2, 1234), ops.dropout(big, 0.2, 1234)
+    assert torch.equal(d1, d2) and abs(float((d1 == 0).float().mean()) - 0.2) < 0.01
+    assert abs(float(d1.float().mean()) - 1.0) < 0.02
