@@ -18,11 +18,12 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int6
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-// norm_out[0] = sqrt(sumsq); norm_out[1] = min(1, max_norm / (norm + 1e-6))  (max_norm <= 0: coef = 1)
-__global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float* __restrict__ norm_out) {
-    const float n = sqrtf(*sumsq);
+// The buffer holds grad_scale^-1 times the true gradient (sum over ranks: grad_scale = 1/world).
+// norm_out[0] = grad_scale * sqrt(sumsq); norm_out[1] = grad_scale * min(1, max_norm / (norm + 1e-6))  (max_norm <= 0: no clip)
+__global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, float grad_scale, float* __restrict__ norm_out) {
+    const float n = sqrtf(*sumsq) * grad_scale;
     norm_out[0] = n;
-    norm_out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (n + 1e-6f)) : 1.0f;
+    norm_out[1] = grad_scale * (max_norm > 0.f ? fminf(1.0f, max_norm / (n + 1e-6f)) : 1.0f);
 }
 
 __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -48,9 +49,9 @@ extern "C" int mvuld_sumsq(const float* x, int64_t n, float* out, hipStream_t st
     MV_LAUNCH_CHECK("sumsq");
     return 0;
 }
-extern "C" int mvuld_clip_coef(const float* sumsq, float max_norm, float* norm_out, hipStream_t stream) {
+extern "C" int mvuld_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* norm_out, hipStream_t stream) {
     MV_CHECK_ARG(sumsq && norm_out, "clip_coef: null pointer");
-    hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, stream, sumsq, max_norm, norm_out);
+    hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1), 0, stream, sumsq, max_norm, grad_scale, norm_out);
     MV_LAUNCH_CHECK("clip_coef");
     return 0;
 }

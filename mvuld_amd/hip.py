@@ -97,10 +97,53 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Timing:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's instrumented step)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+        self.pending = None
+
+    def enable(self):
+        self.enabled, self.records, self.pending = True, [], None
+
+    def disable(self):
+        self.enabled = False
+
+    def annotate(self, family, flops=0.0, nbytes=0.0):
+        """Name the kernel family and the ALGORITHMIC work of the next call."""
+        if self.enabled:
+            self.pending = (family, float(flops), float(nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, fl, by, e0, e1 in self.records:
+            d = fam.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+            d["flops"] += fl
+            d["bytes"] += by
+        return fam
+
+
+TIMING = _Timing()
+
+
 def call(name, *args):
     """Invoke ``mvuld_<name>`` on the current stream; raise on a non-zero status."""
     fn = LIB.fn("mvuld_" + name)
-    rc = fn(*args, stream())
+    if TIMING.enabled:
+        fam, fl, by = TIMING.pending or (name, 0.0, 0.0)
+        TIMING.pending = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args, stream())
+        e1.record()
+        TIMING.records.append((fam, fl, by, e0, e1))
+    else:
+        rc = fn(*args, stream())
     if rc != 0:
         raise RuntimeError(f"mvuld_{name} failed ({rc}): {last_error()}")
 

@@ -73,7 +73,8 @@ class _BatchNormFn(torch.autograd.Function):
     """BatchNorm1d over dim 1 of [B,C] or [B,C,F] (channel = dim 1), batch statistics when training."""
 
     @staticmethod
-    def forward(ctx, x, bn):
+    def forward(ctx, x, bn, _w):
+        # `_w` (= bn.weight) is passed only so that this node exists in the graph when x needs no gradient
         hip.require_gpu(x)
         x = x.contiguous()
         if x.dim() == 2:
@@ -95,12 +96,13 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, sm, sr = ctx.saved_tensors
         bn, lay, training = ctx.meta
-        return ops.batchnorm_bwd(dy.contiguous(), x, bn.weight, bn.bias, sm, sr, *lay, training), None
+        return ops.batchnorm_bwd(dy.contiguous(), x, bn.weight, bn.bias, sm, sr, *lay, training), None, None
 
 
 class _GATConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, conv, index, training):
+    def forward(ctx, x, conv, index, training, _w):
+        # `_w` (= conv.fc.weight) keeps this node in the graph when x (raw node features) needs no gradient
         hip.require_gpu(x)
         ad = x.dtype
         N = x.shape[0]
@@ -148,7 +150,7 @@ class _GATConvFn(torch.autograd.Function):
             dx = ops.gemm_nt(dft, ops.weight_t(conv.fc.weight, ad))
             if p > 0:
                 dx = ops.dropout(dx, p, seed)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _SegmentPadFn(torch.autograd.Function):
@@ -268,12 +270,16 @@ class GATConv(nn.Module):
         nn.init.xavier_normal_(self.attn_r, gain=gain)
 
     def forward(self, graph, feat):
-        return _GATConvFn.apply(feat, self, graph.index(), self.training)
+        return _GATConvFn.apply(feat, self, graph.index(), self.training, self.fc.weight)
 
 
 def l2norm(X):
     """L2-normalise over dim 1 (reference helper, GraphModel.py:74-79); fused with the mean on the hot path."""
     raise RuntimeError("l2norm is fused into _L2NormMeanFn on the hot path")
+
+
+def batch_norm(x, bn):
+    return _BatchNormFn.apply(x, bn, bn.weight)
 
 
 class Multi_DefectModel_new_GCN(nn.Module):
@@ -320,9 +326,9 @@ class Multi_DefectModel_new_GCN(nn.Module):
         img_embedding = ops.cast(img_embedding.contiguous(), ad) if img_embedding.dtype != ad else img_embedding
         func_text_embedding = ops.cast(func_text_embedding.contiguous(), ad) if func_text_embedding.dtype != ad else func_text_embedding
         # 1. image branch  (:153-154)
-        x = linear_act(_BatchNormFn.apply(img_embedding, self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        x = linear_act(batch_norm(img_embedding, self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
         # 2. text branch   (:158-159)
-        t = linear_act(_BatchNormFn.apply(func_text_embedding, self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        t = linear_act(batch_norm(func_text_embedding, self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
         # 3. graph branch  (:163-177)
         h = g.ndata["_UNIX_NODE_EMB"]
         bboxes = g.ndata["pos_emb"]
@@ -339,12 +345,12 @@ class Multi_DefectModel_new_GCN(nn.Module):
         off = g.index()["node_offsets"]
         h_i = _SegmentPadFn.apply(h, off, B, self.max_node)                      # [B,100,512]
         pos_i = _SegmentPadFn.apply(bboxes, off, B, self.max_node)               # [B,100,4]
-        h_i = linear_act(_BatchNormFn.apply(h_i, self.bn_gat), self.fc_gat.weight, self.fc_gat.bias, "elu")    # [B,100,480]
-        pos_i = linear_act(_BatchNormFn.apply(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")  # [B,100,32]
+        h_i = linear_act(batch_norm(h_i, self.bn_gat), self.fc_gat.weight, self.fc_gat.bias, "elu")    # [B,100,480]
+        pos_i = linear_act(batch_norm(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")  # [B,100,32]
         v = _ConcatColsFn.apply(h_i, pos_i).view(B * self.max_node, 512)          # node rows; no permute needed
         for i in range(1, 9):
             v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
         h_feature = _L2NormMeanFn.apply(v, B)                                     # l2norm over nodes + mean (:201-204)
         all_feats = _ConcatColsFn.apply(x, h_feature, t)
-        return linear_act(_BatchNormFn.apply(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
+        return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
                           None, torch.float32)

@@ -65,6 +65,7 @@ class _PatchEmbedFn(torch.autograd.Function):
         w, b, g, beta = ctx.params
         dy = ops.layernorm_bwd(dout.contiguous(), y, g, beta, mean, rstd)
         ops.linear_wgrad(dy, cols, w, b)
+        ops.fire_backward_done("swin")          # first op of the encoder: every Swin gradient is final now
         return None, None, None, None, None, None
 
 

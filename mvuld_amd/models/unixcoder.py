@@ -72,6 +72,7 @@ class _EmbedFn(torch.autograd.Function):
         call("embed_bwd", ptr(ids), ptr(pos), ptr(draw), ptr(ops.grad_of(emb.word_embeddings.weight)),
              ptr(ops.grad_of(emb.position_embeddings.weight)), ids.numel(), H, cfg.vocab_size, cfg.max_position_embeddings, dt(draw))
         ops.colsum_into(draw, ops.grad_of(emb.token_type_embeddings.weight)[0])
+        ops.fire_backward_done("unixcoder")     # first op of the encoder: every UniXcoder gradient is final now
         return None, None, None, None
 
 

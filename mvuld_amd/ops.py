@@ -18,6 +18,21 @@ FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU 
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
 
 
+# callbacks fired when the LAST backward of an encoder has run, i.e. all its gradients are final (used to start
+# that encoder's gradient all-reduce while the rest of backward is still running)
+_BACKWARD_DONE = {}
+
+
+def on_backward_done(tag, fn):
+    _BACKWARD_DONE[tag] = fn
+
+
+def fire_backward_done(tag):
+    fn = _BACKWARD_DONE.get(tag)
+    if fn is not None:
+        fn()
+
+
 def bump_weight_epoch():
     WEIGHT_EPOCH[0] += 1
 
@@ -81,6 +96,10 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
         ldaux = aux.stride(-2)
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("gemm_nt: bias must be fp32")
+    if hip.TIMING.enabled:
+        mfma = (a.dtype == torch.bfloat16 and K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and sa % 8 == 0 and sb % 8 == 0
+                and M >= 32 and N >= 32 and not FORCE_SIMPLE_GEMM[0])
+        hip.TIMING.annotate("gemm_nt_mfma_bf16" if mfma else "gemm_nt_simple", 2.0 * M * N * K * batch)
     call("gemm_nt", ptr(a), lda, sa, ptr(b), ldb, sb, ptr(out), ldc, sc, M, N, K, batch, ptr(bias), epi, ptr(aux),
          ldaux or 0, saux, float(alpha), out_mode, splitk, dt(a), dt(out), 1 if FORCE_SIMPLE_GEMM[0] else 0)
     return out
@@ -205,12 +224,14 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     lse = torch.empty((g.B * g.nW * g.H * g.N,), dtype=torch.float32, device=qkv.device)
     use_mfma = (ATTN_IMPL[0] == "auto" and qkv.dtype == torch.bfloat16 and hasattr(hip.LIB.load(), "mvuld_attn_fwd_mfma"))
     name = "attn_fwd_mfma" if use_mfma else "attn_fwd_simple"
+    hip.TIMING.annotate(name, 4.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
     return out, lse
 
 
 def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None):
     dqkv = torch.empty_like(qkv)
+    hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
          ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), dt(qkv))
     return dqkv

@@ -57,6 +57,7 @@ class ParamStore:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.norm = torch.zeros(2, dtype=torch.float32, device=device)      # [grad norm, clip coefficient]
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self.grad_scale = 1.0
         for name, p, o, n, _ in self.layout:
             self.flat[o:o + n].copy_(p.data.reshape(-1).to(device))
             p.data = self.flat[o:o + n].view(p.shape)
@@ -86,11 +87,15 @@ class ParamStore:
     def zero_grad(self):
         self.grad.zero_()
 
-    def clip_grad_norm_(self, max_norm):
-        """Global L2 norm of the flat gradient and the clip coefficient, both left on the device (self.norm)."""
+    def clip_grad_norm_(self, max_norm, grad_scale=None):
+        """Global L2 norm of the (grad_scale x) flat gradient and the coefficient the AdamW kernel multiplies the
+        gradient by (grad_scale x clip), both left on the device (self.norm).  grad_scale = 1/world after an
+        all-reduce SUM."""
+        if grad_scale is None:
+            grad_scale = self.grad_scale
         self._sumsq.zero_()
         call("sumsq", ptr(self.grad), self.total, ptr(self._sumsq))
-        call("clip_coef", ptr(self._sumsq), float(max_norm) if max_norm else 0.0, ptr(self.norm))
+        call("clip_coef", ptr(self._sumsq), float(max_norm) if max_norm else 0.0, float(grad_scale), ptr(self.norm))
         return self.norm[0]
 
 

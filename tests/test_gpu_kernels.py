@@ -142,7 +142,7 @@ def test_batchnorm(gpu, dtype, shape, training):
     ref = bn(xr)
     ref.backward(dy)
     xg = dev(x, dtype).requires_grad_(True)
-    y = _BatchNormFn.apply(xg, gb)
+    y = _BatchNormFn.apply(xg, gb, gb.weight)
     y.backward(dev(dy, dtype))
     assert rel(y, ref) < tol(dtype)
     assert rel(xg.grad, xr.grad) < tol(dtype)
@@ -348,7 +348,7 @@ def test_cross_entropy_adamw_sumsq(gpu):
     ss = torch.zeros(1, device=gpu); no = torch.zeros(2, device=gpu)
     call("sumsq", ptr(G), n, ptr(ss))
     assert rel(ss, (g0 ** 2).sum()) < 1e-5
-    call("clip_coef", ptr(ss), float(g0.norm() * 0.5), ptr(no))
+    call("clip_coef", ptr(ss), float(g0.norm() * 0.5), 1.0, ptr(no))
     for step in (1, 2, 3):
         opt.step()
         call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, step, ptr(no))
