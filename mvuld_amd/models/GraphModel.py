@@ -198,6 +198,23 @@ class _L2NormMeanFn(torch.autograd.Function):
         return dg, None
 
 
+class _CastFn(torch.autograd.Function):
+    """storage-dtype change that autograd can see (bf16 encoders -> fp32 tail and back)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, d):
+        return ops.cast(d.contiguous(), ctx.src), None
+
+
+def cast_to(x, dtype):
+    return x if x.dtype == dtype else _CastFn.apply(x, dtype)
+
+
 class _ConcatColsFn(torch.autograd.Function):
     """cat along the last dim through device copies (memory movement only)."""
 
@@ -291,6 +308,7 @@ class Multi_DefectModel_new_GCN(nn.Module):
         self.config = config
         self.num_classes = config.MODEL.NUM_CLASSES
         self.act_dtype = act_dtype
+        self.tail_fp32 = True
         hfeat, embfeat, numheads = 512, 768, 4
         self.p_gat, self.p_mlp, self.p_hidden = 0.2, 0.2, 0.2
         self.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
@@ -348,9 +366,14 @@ class Multi_DefectModel_new_GCN(nn.Module):
         h_i = linear_act(batch_norm(h_i, self.bn_gat), self.fc_gat.weight, self.fc_gat.bias, "elu")    # [B,100,480]
         pos_i = linear_act(batch_norm(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")  # [B,100,32]
         v = _ConcatColsFn.apply(h_i, pos_i).view(B * self.max_node, 512)          # node rows; no permute needed
+        # The 8-block Rs_GCN chain, the eps-free l2norm over nodes and the final BatchNorm are <1 % of the FLOPs but
+        # numerically the touchiest part of the model (a residual chain feeding a difference of near-equal terms):
+        # they run with fp32 storage even when the encoders run in bf16.
+        tail = torch.float32 if self.tail_fp32 else ad
+        v = cast_to(v, tail)
         for i in range(1, 9):
             v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
         h_feature = _L2NormMeanFn.apply(v, B)                                     # l2norm over nodes + mean (:201-204)
-        all_feats = _ConcatColsFn.apply(x, h_feature, t)
+        all_feats = _ConcatColsFn.apply(cast_to(x, tail), h_feature, cast_to(t, tail))
         return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
                           None, torch.float32)

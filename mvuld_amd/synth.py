@@ -76,6 +76,10 @@ def synth_param(name: str, shape, salt=0) -> torch.Tensor:
         return tensor(name, shape, -0.05, 0.05, salt)
     if len(shape) <= 1:
         # every 1-D "weight" on this path is a LayerNorm / BatchNorm scale
+        if leaf == "weight" and ".W.1." in name:
+            # Rs_GCN's residual BatchNorm scale: zero at init in the reference (Rs_GCN.py:33), small after training.
+            # Non-zero so the GCN kernels are exercised, small so the 8-block residual chain stays well conditioned.
+            return tensor(name, shape, 0.05, 0.15, salt)
         if leaf == "weight":
             return tensor(name, shape, 0.75, 1.25, salt)
         return tensor(name, shape, -0.05, 0.05, salt)      # biases, q_bias, v_bias, norm biases
