@@ -1,0 +1,796 @@
+// Fused attention on the CDNA4 matrix cores (bf16 storage, fp32 accumulate): forward, dQ pass, dK/dV pass.
+// Same contract as the VALU kernels in attention.hip (MODE 0 SwinV2 window attention with cosine scores +
+// continuous position bias + shift mask and the roll/partition index map; MODE 1 pad-masked attention).
+//
+// Tiling (v_mfma_f32_16x16x32_bf16; one workgroup of 8 waves per (window|sequence, head), staged ONCE):
+//   forward / dQ : a wave walks 16-QUERY tiles.  S^T = K_tile . Q^T puts the query on the lane (column) and 4 keys per
+//     16x16 tile in its registers, so the softmax statistics are lane-local up to a 4-lane reduce (two v_permlane*_swap,
+//     no LDS), and two S^T tiles (32 keys) ARE the B operand of the next product (O^T = V^T . P^T, dQ^T = K^T . dS^T)
+//     with no cross-lane movement -- the k-slot permutation (slot (g,j<4) <-> key 4g+j, slot (g,j>=4) <-> key 16+4g+j-4)
+//     is applied to the A operand instead, which is read TRANSPOSED straight out of the row-major LDS image with
+//     ds_read_b64_tr_b16 (gfx950's 4x16 hardware transpose read).
+//   dK/dV : a wave walks 16-KEY tiles; S = Q_tile . K^T and dP = dO_tile . V^T put the key on the lane, and P / dS are
+//     the B operands of dV^T = dO^T . P and dK^T = Q~^T . dS (A = transposed reads of the dO / Q~ images).
+// LDS holds K (normalised for MODE 0) and V row-major (forward, dQ pass) or Q~ and dO (dK/dV pass): 2 x N x (hd+8) bf16
+// (128 KB at N=784, hd=32), plus per-row info, and for MODE 0 the head's (2w-1)^2 fp32 bias table (+ its gradient):
+// up to ~155 KB of the 160 KB.  The shift mask comes from 3x3 region ids: no [N,N] tensor ever exists.  P is recomputed
+// in backward from the saved log-sum-exp; delta = rowsum(dO * O) comes from a small pre-kernel.  d(bias table) is
+// accumulated with LDS float atomics per workgroup and flushed with one global atomic per touched entry.
+#include "common.h"
+
+struct AttnGeom {
+    int mode, B, H, N, nW, res, ws, shift;
+    float scale;
+};
+
+typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
+typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
+typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+
+#define LN100 4.605170185988092f
+#define NEG_BIG -1.0e30f
+
+__device__ __forceinline__ int64_t am_token(const AttnGeom& g, int b, int w, int n) {
+    if (g.mode == 1) return (int64_t)b * g.N + n;
+    const int nwx = g.res / g.ws;
+    const int sy = (w / nwx) * g.ws + n / g.ws, sx = (w % nwx) * g.ws + n % g.ws;
+    int oy = sy + g.shift, ox = sx + g.shift;
+    if (oy >= g.res) oy -= g.res;
+    if (ox >= g.res) ox -= g.res;
+    return ((int64_t)b * g.res + oy) * g.res + ox;
+}
+__device__ __forceinline__ int am_rid(const AttnGeom& g, int s) { return s < g.res - g.ws ? 0 : (s < g.res - g.shift ? 1 : 2); }
+// per-token info word.  MODE 0: (iy*(2ws-1)+ix) | region << 16 ; MODE 1: validity in bit 0.  Bit 30 marks a padding row
+// (all other fields then hold safe in-range values, so the hot loops stay branch-free).
+#define AM_PAD (1 << 30)
+__device__ __forceinline__ int am_info(const AttnGeom& g, const int* __restrict__ valid, int b, int w, int n) {
+    if (n >= g.N) return AM_PAD;
+    if (g.mode == 1) return valid[b * g.N + n] ? 1 : 0;
+    const int nwx = g.res / g.ws;
+    const int iy = n / g.ws, ix = n % g.ws;
+    int reg = 0;
+    if (g.shift > 0) reg = am_rid(g, (w / nwx) * g.ws + iy) * 3 + am_rid(g, (w % nwx) * g.ws + ix);
+    return (iy * (2 * g.ws - 1) + ix) | (reg << 16);
+}
+
+// reductions over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48 -- VALU only (v_permlane16/32_swap)
+__device__ __forceinline__ float sum4g(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float max4g(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+union U8 { uint4 u; bf16x8_t v; bf16 e[8]; };
+union U4 { uint2 u; bf16x4_t v; bf16 e[4]; };
+
+// Stage `rows` token rows (HD wide, from column `coloff` of a [tokens, rowstride] matrix) starting at n0 into the
+// row-major LDS image rm[rows][HD+8], with optional L2 normalisation and scale.  Rows >= N are zero.  Four 16-byte loads
+// are kept in flight per thread.
+template <int HD>
+__device__ __forceinline__ void stage_tile(const AttnGeom& g, const bf16* __restrict__ base, int64_t rowstride, int coloff, int b,
+                                           int w, int n0, int rows, bf16* rm, bool normalize, float mul) {
+    constexpr int CPR = HD / 8;
+    const int total = rows * CPR;
+    for (int c0 = threadIdx.x; c0 < total; c0 += 4 * blockDim.x) {
+        U8 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * blockDim.x;
+            const int n = n0 + c / CPR;
+            x[u].u = make_uint4(0, 0, 0, 0);
+            if (c < total && n < g.N) x[u].u = *(const uint4*)(base + am_token(g, b, w, n) * rowstride + coloff + (c % CPR) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * blockDim.x;
+            if (normalize || mul != 1.0f) {
+                float f[8];
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = (float)x[u].e[e]; ss += f[e] * f[e]; }
+                float sc = mul;
+                if (normalize) {
+#pragma unroll
+                    for (int o = 1; o < CPR; o <<= 1) ss += __shfl_xor(ss, o, 64);
+                    sc = mul / fmaxf(sqrtf(ss), 1e-12f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[u].e[e] = (bf16)(f[e] * sc);
+            }
+            if (c < total) *(uint4*)(rm + (c / CPR) * (HD + 8) + (c % CPR) * 8) = x[u].u;
+        }
+    }
+}
+
+// A operand = transposed 16(dims d0..d0+15) x 32(row slots) fragment of a row-major image rm[rows][ld]:
+// k-slot (g, j<4) <-> row r0+4g+j, (g, j>=4) <-> row r0+16+4g+j-4.  ds_read_b64_tr_b16: within each group of 16 lanes,
+// lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
+__device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int ld, int d0, int r0, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+    const int fg = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* a0 = rm + (r0 + 4 * fg + q) * ld + d0 + 4 * pp;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)a0);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 16 * ld));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid.x = B*nW*H*qsplit: workgroup (bwh, part) stages K,V of (window, head) once and walks the q tiles  part, part+qsplit, ...
+template <int HD, int MODE>
+__global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+                                                       const float* __restrict__ logit_scale, const int* __restrict__ valid,
+                                                       bf16* __restrict__ out, float* __restrict__ lse, int Npad, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KLD = HD + 8;
+    bf16* Ks = (bf16*)smem;                       // [Npad][KLD]  (normalised for MODE 0)
+    bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
+    int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
+    float* tab = (float*)(Kinfo + Npad);          // MODE 0: [(2ws-1)^2]
+    const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
+    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
+    const int C = g.H * HD;
+    const int64_t rs = 3 * (int64_t)C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Kinfo[i] = am_info(g, valid, b, w, i);
+    int C0 = 0;
+    float tau = 1.f;
+    if (MODE == 0) {
+        const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
+        tau = __expf(fminf(logit_scale[h], LN100));
+    }
+    __syncthreads();
+
+    const int ntile = (g.N + 15) / 16;
+    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * 8) {
+        const int nq = qt * 16 + fc;
+        const bool qok = nq < g.N;
+        const int nqc = qok ? nq : g.N - 1;
+        const int64_t tq = am_token(g, b, w, nqc);
+        const int qinf = am_info(g, valid, b, w, nqc);
+        const int bq = (qinf & 0xffff) + C0, regq = (qinf >> 16) & 0xff;
+        bf16x8_t qf[HD / 32];
+        {
+            float f[HD / 32][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                U8 x;
+                x.u = *(const uint4*)(qkv + tq * rs + h * HD + ks * 32 + fg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
+            }
+            float sc = g.scale;
+            if (MODE == 0) sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)(f[ks][e] * sc);
+        }
+        float m = -INFINITY, l = 0.f;
+        f32x4_t oacc[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kb = 0; kb < Npad; kb += 32) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const bf16x8_t a0 = *(const bf16x8_t*)(Ks + (kb + fc) * KLD + ks * 32 + fg * 8);
+                const bf16x8_t a1 = *(const bf16x8_t*)(Ks + (kb + 16 + fc) * KLD + ks * 32 + fg * 8);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[ks], s1, 0, 0, 0);
+            }
+            const int4 i0 = *(const int4*)(Kinfo + kb + 4 * fg);
+            const int4 i1 = *(const int4*)(Kinfo + kb + 16 + 4 * fg);
+            const int ki[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+            float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            float bm = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float v = s[r];
+                if (MODE == 0) {
+                    v += tab[bq - (ki[r] & 0xffff)];
+                    v = (((ki[r] >> 16) & 0xff) != regq) ? v - 100.0f : v;
+                } else {
+                    v = (qinf & ki[r] & 1) ? v : v - 10000.0f;
+                }
+                s[r] = (ki[r] & AM_PAD) ? NEG_BIG : v;
+                bm = fmaxf(bm, s[r]);
+            }
+            bm = max4g(bm);
+            const float mn = fmaxf(m, bm);
+            const float alpha = __expf(m - mn);
+            bf16x8_t pb;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float p = __expf(s[r] - mn);
+                ps += p;
+                pb[r] = (bf16)p;
+            }
+            l = l * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                oacc[d] *= alpha;
+                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Vs, KLD, d * 16, kb, lane), pb, oacc[d], 0, 0, 0);
+            }
+            m = mn;
+        }
+        l = sum4g(l);
+        if (qok) {
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(oacc[d][r] * inv);
+                *(uint2*)(out + tq * C + h * HD + d * 16 + 4 * fg) = o.u;
+            }
+            if (fg == 0) lse[((int64_t)bw * g.H + h) * g.N + nq] = m + __logf(l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ void attn_delta_k(const bf16* __restrict__ out, const bf16* __restrict__ dout, float* __restrict__ delta, int64_t ntok, int H, int hd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // over tokens * H
+    if (i >= ntok * H) return;
+    const bf16* o = out + i * hd;
+    const bf16* d = dout + i * hd;
+    float s = 0.f;
+    for (int e = 0; e < hd; e += 8) {
+        U8 a, c;
+        a.u = *(const uint4*)(o + e);
+        c.u = *(const uint4*)(d + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (float)a.e[k] * (float)c.e[k];
+    }
+    delta[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ d table, d logit_scale)
+template <int HD, int MODE>
+__global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+                                                          const float* __restrict__ logit_scale, const int* __restrict__ valid,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                          float* __restrict__ dtable16, float* __restrict__ dlogit_scale, int Npad, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KLD = HD + 8;
+    bf16* Ks = (bf16*)smem;                       // [Npad][KLD]
+    bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
+    int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
+    float* red = (float*)(Kinfo + Npad);          // [8]
+    float* tab = red + 8;                         // MODE 0: [T2]
+    const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
+    const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
+    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
+    const int C = g.H * HD;
+    const int64_t rs = 3 * (int64_t)C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Kinfo[i] = am_info(g, valid, b, w, i);
+    int C0 = 0;
+    float tau = 1.f;
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
+        tau = __expf(fminf(logit_scale[h], LN100));
+    }
+    __syncthreads();
+
+    float dtau_part = 0.f;
+    const int ntile = (g.N + 15) / 16;
+    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * 8) {
+        const int nq = qt * 16 + fc;
+        const bool qok = nq < g.N;
+        const int nqc = qok ? nq : g.N - 1;
+        const int64_t tq = am_token(g, b, w, nqc);
+        const int qinf = am_info(g, valid, b, w, nqc);
+        const int bq = (qinf & 0xffff) + C0, regq = (qinf >> 16) & 0xff;
+        bf16x8_t qf[HD / 32], dof[HD / 32];
+        {
+            float f[HD / 32][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                U8 x, y;
+                x.u = *(const uint4*)(qkv + tq * rs + h * HD + ks * 32 + fg * 8);
+                y.u = qok ? *(const uint4*)(dout + tq * C + h * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
+                dof[ks] = y.v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
+            }
+            float sc = g.scale;
+            if (MODE == 0) sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)(f[ks][e] * sc);
+        }
+        const float Lq = lse[((int64_t)bw * g.H + h) * g.N + nqc];
+        const float Dq = qok ? delta[tq * g.H + h] : 0.f;
+        f32x4_t dq[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kb = 0; kb < Npad; kb += 32) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const int o0 = (kb + fc) * KLD + ks * 32 + fg * 8, o1 = (kb + 16 + fc) * KLD + ks * 32 + fg * 8;
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o0), qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o1), qf[ks], s1, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o0), dof[ks], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o1), dof[ks], p1, 0, 0, 0);
+            }
+            const int4 i0 = *(const int4*)(Kinfo + kb + 4 * fg);
+            const int4 i1 = *(const int4*)(Kinfo + kb + 16 + 4 * fg);
+            const int ki[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            bf16x8_t dsb;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float sv = s[r];
+                if (MODE == 0) {
+                    sv += tab[bq - (ki[r] & 0xffff)];
+                    sv = (((ki[r] >> 16) & 0xff) != regq) ? sv - 100.0f : sv;
+                } else {
+                    sv = (qinf & ki[r] & 1) ? sv : sv - 10000.0f;
+                }
+                // padding keys contribute nothing; padding queries have dO = 0 and delta = 0, hence ds = 0
+                const float ds = (ki[r] & AM_PAD) ? 0.f : __expf(sv - Lq) * (dp[r] - Dq);
+                dsb[r] = (bf16)ds;
+            }
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ks, KLD, d * 16, kb, lane), dsb, dq[d], 0, 0, 0);
+        }
+        // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]
+        if (MODE == 0) {
+            float qh[HD / 16][4];
+            float ss = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 x;
+                x.u = *(const uint2*)(qkv + tq * rs + h * HD + d * 16 + 4 * fg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { qh[d][r] = (float)x.e[r]; ss += qh[d][r] * qh[d][r]; }
+            }
+            const float qinv = 1.0f / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { qh[d][r] *= qinv; dot += dq[d][r] * qh[d][r]; }
+            if (qok) dtau_part += dot;
+            dot = sum4g(dot) * tau;                   // q^ . d(q^)
+            if (qok) {
+#pragma unroll
+                for (int d = 0; d < HD / 16; ++d) {
+                    U4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.e[r] = (bf16)((tau * dq[d][r] - qh[d][r] * dot) * qinv);
+                    *(uint2*)(dqkv + tq * rs + h * HD + d * 16 + 4 * fg) = o.u;
+                }
+            }
+        } else if (qok) {
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(dq[d][r] * g.scale);
+                *(uint2*)(dqkv + tq * rs + h * HD + d * 16 + 4 * fg) = o.u;
+            }
+        }
+    }
+    if (MODE == 0) {
+        dtau_part = wave_sum(dtau_part);
+        if (lane == 0) red[wave] = dtau_part;
+        __syncthreads();
+        if (threadIdx.x == 0 && logit_scale[h] < LN100) {
+            float t = 0.f;
+            for (int i = 0; i < 8; ++i) t += red[i];
+            atomicAdd(dlogit_scale + h, t * tau);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: d(bias table)  (MODE 0)
+// dB[dy,dx] = sum over windows and over (q,k) with (yq-yk, xq-xk) = (dy,dx) of dS[q,k].  Per-element LDS float atomics run at
+// ~1 lane/clk/CU and cost 2.5x the whole rest of the backward, so this pass walks the pairs in an order that makes the table
+// entry of every (lane, register) LOOP-INVARIANT: tiles are aligned to image rows of the window (a q tile = up to 16 tokens of
+// one row, a key block = one row padded to 32 slots), a wave owns one (dy, q-part) and sweeps yq with yk = yq - dy, so dS is
+// summed in 8 registers per lane and only the final sums touch LDS / global atomics (~14x fewer atomics at w = 28).
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+                                                             const float* __restrict__ logit_scale, const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             float* __restrict__ dtable16, int Npad, int split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KLD = HD + 8;
+    bf16* Ks = (bf16*)smem;                       // [Npad][KLD] normalised keys
+    bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
+    int* Ktok = (int*)(Vs + (size_t)Npad * KLD);  // [Npad] token index of every window position
+    float* tab = (float*)(Ktok + Npad);           // [T2]
+    const int W2 = 2 * g.ws - 1, T2 = W2 * W2;
+    float* dtab = tab + T2;                       // [T2]
+    const int part = blockIdx.x % split, bwh = blockIdx.x / split;
+    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
+    const int C = g.H * HD;
+    const int64_t rs = 3 * (int64_t)C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int ws = g.ws;
+
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Ktok[i] = (int)am_token(g, b, w, min(i, g.N - 1));
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = table16[(int64_t)i * g.H + h]; dtab[i] = 0.f; }
+    const float tau = __expf(fminf(logit_scale[h], LN100));
+    __syncthreads();
+
+    const int nqp = (ws + 15) / 16;               // q parts per image row
+    const int qw = (ws + nqp - 1) / nqp;          // tokens per q part (<= 16)
+    const int nitem = W2 * nqp;                   // (dy, q part)
+    // key slots of this lane: tile t, row 4*fg + r  ->  xk = 16 t + 4 fg + r
+    for (int item = part + split * wave; item < nitem; item += split * 8) {
+        const int dy = item / nqp - (ws - 1), qp = item % nqp;
+        const int xq = qp * qw + fc;
+        const bool qv = fc < qw && xq < ws;
+        const int y0 = max(0, dy), y1 = min(ws, ws + dy);       // yq range with 0 <= yq - dy < ws
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        // Everything that depends only on (lane, register) is hoisted out of the row sweep: the table entry (hence the
+        // bias value) and the x-part of the shift-mask region test.  The y-part of the region test is wave-uniform.
+        const int xqc = min(xq, ws - 1);
+        const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
+        const int rxq = g.shift > 0 ? am_rid(g, wx * ws + xqc) : 0;
+        float bias[8];
+        bool xdiff[8], kval[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
+            const int xkc = min(xk, ws - 1);
+            bias[r] = tab[(dy + ws - 1) * W2 + (xqc - xkc + ws - 1)];
+            xdiff[r] = g.shift > 0 && am_rid(g, wx * ws + xkc) != rxq;
+            kval[r] = xk < ws;
+        }
+        // software pipeline: the q-side operands of row yq+1 are fetched from global while row yq is being processed
+        U8 nx, ny;
+        float nL = 0.f, nD = 0.f;
+        auto fetch = [&](int yq) {
+            const int nq = yq * ws + xqc;
+            const int64_t tq = Ktok[nq];
+            nx.u = *(const uint4*)(qkv + tq * rs + h * HD + fg * 8);
+            ny.u = qv ? *(const uint4*)(dout + tq * C + h * HD + fg * 8) : make_uint4(0, 0, 0, 0);
+            nL = lse[((int64_t)bw * g.H + h) * g.N + nq];
+            nD = qv ? delta[tq * g.H + h] : 0.f;
+        };
+        if (y0 < y1) fetch(y0);
+        for (int yq = y0; yq < y1; ++yq) {
+            const int yk = yq - dy;
+            const U8 x = nx;
+            const bf16x8_t dof = ny.v;
+            const float Lq = nL, Dq = nD;
+            if (yq + 1 < y1) fetch(yq + 1);
+            const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yq) != am_rid(g, wy * ws + yk);     // wave-uniform
+            bf16x8_t qf;
+            {
+                float f[8];
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = (float)x.e[e]; ss += f[e] * f[e]; }
+                const float sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[e] = (bf16)(f[e] * sc);
+            }
+            // A rows: key slot (t, fc) -> token yk*ws + min(16 t + fc, ws-1)
+            const int k0 = yk * ws + min(fc, ws - 1), k1 = yk * ws + min(16 + fc, ws - 1);
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k0 * KLD + fg * 8), qf, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k1 * KLD + fg * 8), qf, s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k0 * KLD + fg * 8), dof, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k1 * KLD + fg * 8), dof, p1, 0, 0, 0);
+            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float sv = s[r] + bias[r];
+                sv = (ydiff || xdiff[r]) ? sv - 100.0f : sv;
+                const float ds = __expf(sv - Lq) * (dp[r] - Dq);
+                acc[r] += kval[r] ? ds : 0.f;
+            }
+        }
+        if (qv) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
+                if (xk < ws) atomicAdd(dtab + (dy + ws - 1) * W2 + (xq - xk + ws - 1), acc[r]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) {
+        const float v = dtab[i];
+        if (v != 0.f) atomicAdd(dtable16 + (int64_t)i * g.H + h, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int HD, int MODE>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+                                                           const float* __restrict__ logit_scale, const int* __restrict__ valid,
+                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv, int Npad, int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KLD = HD + 8;
+    bf16* Qs = (bf16*)smem;                       // [Npad][KLD]   q~
+    bf16* Ds = Qs + (size_t)Npad * KLD;           // [Npad][KLD]   dO
+    float* Ql = (float*)(Ds + (size_t)Npad * KLD);// [Npad] lse
+    float* Qd = Ql + Npad;                        // [Npad] delta
+    int* Qi = (int*)(Qd + Npad);                  // [Npad] info
+    float* tab = (float*)(Qi + Npad);             // MODE 0: [T2]
+    const int part = blockIdx.x % ksplit, bwh = blockIdx.x / ksplit;
+    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
+    const int C = g.H * HD;
+    const int64_t rs = 3 * (int64_t)C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    int C0 = 0;
+    float qmul = g.scale;
+    if (MODE == 0) {
+        const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
+        qmul = __expf(fminf(logit_scale[h], LN100));
+    }
+    stage_tile<HD>(g, qkv, rs, h * HD, b, w, 0, Npad, Qs, MODE == 0, qmul);
+    stage_tile<HD>(g, dout, C, h * HD, b, w, 0, Npad, Ds, false, 1.0f);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        const int inf = am_info(g, valid, b, w, i);
+        Qi[i] = MODE == 0 ? (((inf & 0xffff) + C0) | (inf & ~0xffff)) : inf;
+        float L = 0.f, D = 0.f;
+        if (i < g.N) {
+            L = lse[((int64_t)bw * g.H + h) * g.N + i];
+            D = delta[am_token(g, b, w, i) * g.H + h];
+        }
+        Ql[i] = L;
+        Qd[i] = D;
+    }
+    __syncthreads();
+
+    const int ntile = (g.N + 15) / 16;
+    for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * 8) {
+        const int nk = kt * 16 + fc;
+        const bool kok = nk < g.N;
+        const int nkc = kok ? nk : g.N - 1;
+        const int64_t tk = am_token(g, b, w, nkc);
+        const int kinf = kok ? am_info(g, valid, b, w, nkc) : AM_PAD;
+        const int bk = kinf & 0xffff, regk = (kinf >> 16) & 0xff;
+        bf16x8_t kf[HD / 32], vf[HD / 32];
+        {
+            float f[HD / 32][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                U8 x, y;
+                x.u = *(const uint4*)(qkv + tk * rs + C + h * HD + ks * 32 + fg * 8);
+                y.u = *(const uint4*)(qkv + tk * rs + 2 * C + h * HD + ks * 32 + fg * 8);
+                vf[ks] = y.v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
+            }
+            const float sc = MODE == 0 ? 1.0f / fmaxf(sqrtf(sum4g(ss)), 1e-12f) : 1.0f;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[ks][e] = (bf16)(f[ks][e] * sc);
+        }
+        f32x4_t dk[HD / 16], dv[HD / 16];
+#pragma unroll
+        for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
+
+        for (int qb = 0; qb < Npad; qb += 32) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+                const int o0 = (qb + fc) * KLD + ks * 32 + fg * 8, o1 = (qb + 16 + fc) * KLD + ks * 32 + fg * 8;
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o0), kf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o1), kf[ks], s1, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o0), vf[ks], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o1), vf[ks], p1, 0, 0, 0);
+            }
+            const int4 i0 = *(const int4*)(Qi + qb + 4 * fg), i1 = *(const int4*)(Qi + qb + 16 + 4 * fg);
+            const float4 l0 = *(const float4*)(Ql + qb + 4 * fg), l1 = *(const float4*)(Ql + qb + 16 + 4 * fg);
+            const float4 d0 = *(const float4*)(Qd + qb + 4 * fg), d1 = *(const float4*)(Qd + qb + 16 + 4 * fg);
+            const int qi[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+            const float L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            const float D[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            bf16x8_t pb, dsb;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float sv = s[r];
+                if (MODE == 0) {
+                    sv += tab[(qi[r] & 0xffff) - bk];
+                    sv = (((qi[r] >> 16) & 0xff) != regk) ? sv - 100.0f : sv;
+                } else {
+                    sv = (qi[r] & kinf & 1) ? sv : sv - 10000.0f;
+                }
+                const float p = ((qi[r] | kinf) & AM_PAD) ? 0.f : __expf(sv - L[r]);
+                pb[r] = (bf16)p;
+                dsb[r] = (bf16)(p * (dp[r] - D[r]));
+            }
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ds, KLD, d * 16, qb, lane), pb, dv[d], 0, 0, 0);
+                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Qs, KLD, d * 16, qb, lane), dsb, dk[d], 0, 0, 0);
+            }
+        }
+        // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc
+        if (kok) {
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)dv[d][r];
+                *(uint2*)(dqkv + tk * rs + 2 * C + h * HD + d * 16 + 4 * fg) = o.u;
+            }
+        }
+        if (MODE == 0) {
+            float kh[HD / 16][4];
+            float ss = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 x;
+                x.u = *(const uint2*)(qkv + tk * rs + C + h * HD + d * 16 + 4 * fg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { kh[d][r] = (float)x.e[r]; ss += kh[d][r] * kh[d][r]; }
+            }
+            const float kinv = 1.0f / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { kh[d][r] *= kinv; dot += dk[d][r] * kh[d][r]; }
+            dot = sum4g(dot);
+            if (kok) {
+#pragma unroll
+                for (int d = 0; d < HD / 16; ++d) {
+                    U4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.e[r] = (bf16)((dk[d][r] - kh[d][r] * dot) * kinv);
+                    *(uint2*)(dqkv + tk * rs + C + h * HD + d * 16 + 4 * fg) = o.u;
+                }
+            }
+        } else if (kok) {
+#pragma unroll
+            for (int d = 0; d < HD / 16; ++d) {
+                U4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)dk[d][r];
+                *(uint2*)(dqkv + tk * rs + C + h * HD + d * 16 + 4 * fg) = o.u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static int am_check(const char* fn, int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift) {
+    MV_CHECK_ARG(mode == 0 || mode == 1, "%s: mode %d", fn, mode);
+    MV_CHECK_ARG(B > 0 && H > 0 && N > 0 && nW > 0, "%s: empty geometry", fn);
+    MV_CHECK_ARG(hd == 32 || hd == 64, "%s: head_dim %d unsupported (32|64)", fn, hd);
+    if (mode == 0) {
+        MV_CHECK_ARG(ws > 0 && ws < 128 && res % ws == 0 && N == ws * ws && nW == (res / ws) * (res / ws), "%s: window geometry", fn);
+        MV_CHECK_ARG(shift >= 0 && shift < ws, "%s: shift %d", fn, shift);
+    } else {
+        MV_CHECK_ARG(nW == 1, "%s: pad mode needs nW=1", fn);
+    }
+    MV_CHECK_ARG((int64_t)B * nW * H * 8 < 2147483647LL, "%s: grid", fn);
+    return 0;
+}
+
+template <typename F>
+static int am_set_lds(F fn, size_t bytes, const char* name) {
+    MV_CHECK_ARG(bytes <= 160 * 1024, "%s: needs %zu bytes of LDS (> 160 KiB): sequence / window too long for this kernel", name, bytes);
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        mvuld_set_error("%s: hipFuncSetAttribute(%zu) failed", name, bytes);
+        return 1;
+    }
+    return 0;
+}
+
+// enough workgroups to fill 256 CUs a few times over when (windows x heads) alone is small
+static int am_split(int64_t groups, int ntile) {
+    int s = 1;
+    while (groups * s < 1024 && s * 2 * 8 <= ntile) s *= 2;
+    return s;
+}
+
+#define AM_LAUNCH(KERNEL, HDV, MODEV, bytes, ...)                                                \
+    do {                                                                                          \
+        if (am_set_lds(KERNEL<HDV, MODEV>, bytes, #KERNEL)) return 1;                             \
+        hipLaunchKernelGGL((KERNEL<HDV, MODEV>), grid, dim3(512), bytes, stream, __VA_ARGS__);    \
+    } while (0)
+
+#define AM_DISPATCH(KERNEL, bytes, ...)                                      \
+    do {                                                                      \
+        if (hd == 32 && mode == 0) AM_LAUNCH(KERNEL, 32, 0, bytes, __VA_ARGS__);      \
+        else if (hd == 64 && mode == 0) AM_LAUNCH(KERNEL, 64, 0, bytes, __VA_ARGS__); \
+        else if (hd == 32) AM_LAUNCH(KERNEL, 32, 1, bytes, __VA_ARGS__);              \
+        else AM_LAUNCH(KERNEL, 64, 1, bytes, __VA_ARGS__);                            \
+    } while (0)
+
+extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
+                                   const void* qkv, const float* table16, const float* logit_scale, const int* valid, void* out,
+                                   float* lse, int dtype, hipStream_t stream) {
+    if (am_check("attn_fwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
+    MV_CHECK_ARG(dtype == MVULD_BF16, "attn_fwd_mfma: bf16 storage only");
+    MV_CHECK_ARG(qkv && out && lse && (mode == 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale};
+    const int Npad = (N + 31) / 32 * 32;
+    const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
+    const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)T2 * 4;
+    const int qsplit = am_split((int64_t)B * nW * H, (N + 15) / 16);
+    dim3 grid(B * nW * H * qsplit);
+    AM_DISPATCH(attn_fwd_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (bf16*)out, lse, Npad, qsplit);
+    MV_LAUNCH_CHECK("attn_fwd_mfma");
+    return 0;
+}
+
+// workspace: delta [tokens * H] fp32 (caller-owned).  dqkv is fully written.
+extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
+                                   const void* qkv, const float* table16, const float* logit_scale, const int* valid,
+                                   const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
+                                   float* dlogit_scale, float* ws_delta, int dtype, hipStream_t stream) {
+    if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
+    MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
+    MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
+    MV_CHECK_ARG(mode == 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale), "attn_bwd_mfma: null pointer");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale};
+    const int Npad = (N + 31) / 32 * 32;
+    const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
+    const int64_t ntok = (int64_t)B * nW * N;
+    hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H, 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
+                       ws_delta, ntok, H, hd);
+    const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
+    dim3 grid(B * nW * H * split);
+    {
+        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 32 + (size_t)T2 * 4;
+        AM_DISPATCH(attn_bwd_dq_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta,
+                    (bf16*)dqkv, dtable16, dlogit_scale, Npad, split);
+    }
+    {
+        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 12 + (size_t)T2 * 4;
+        AM_DISPATCH(attn_bwd_dkv_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta,
+                    (bf16*)dqkv, Npad, split);
+    }
+    if (mode == 0) {
+        MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
+        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
+        const int items = (2 * ws - 1) * ((ws + 15) / 16);
+        int sp = 1;
+        while ((int64_t)B * nW * H * sp < 1024 && sp * 2 * 8 <= items) sp *= 2;
+        if (am_set_lds(attn_bwd_dbias_mfma_k<32>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
+        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv, table16,
+                           logit_scale, (const bf16*)dout, lse, ws_delta, dtable16, Npad, sp);
+    }
+    MV_LAUNCH_CHECK("attn_bwd_mfma");
+    return 0;
+}

@@ -218,12 +218,23 @@ class AttnGeom:
         return (self.mode, self.B, self.H, self.hd, self.N, self.nW, self.res, self.ws, self.shift, float(self.scale))
 
 
+def _mfma_attn_ok(g: AttnGeom, dtype):
+    """The matrix-core kernels keep K and V (or Q~ and dO) of one (window, head) resident in LDS: <= 160 KiB."""
+    if ATTN_IMPL[0] != "auto" or dtype != torch.bfloat16:
+        return False
+    npad = (g.N + 31) // 32 * 32
+    t2 = (2 * g.ws - 1) ** 2 if g.mode == 0 else 0
+    need = max(2 * npad * (g.hd + 8) * 2 + npad * 4 + 32 + 2 * t2 * 4, 2 * npad * (g.hd + 8) * 2 + npad * 12 + t2 * 4)
+    if g.mode == 0 and (g.hd != 32 or g.ws > 32):
+        return False
+    return need <= 160 * 1024
+
+
 def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     tokens = qkv.shape[0]
     out = torch.empty((tokens, g.H * g.hd), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((g.B * g.nW * g.H * g.N,), dtype=torch.float32, device=qkv.device)
-    use_mfma = (ATTN_IMPL[0] == "auto" and qkv.dtype == torch.bfloat16 and hasattr(hip.LIB.load(), "mvuld_attn_fwd_mfma"))
-    name = "attn_fwd_mfma" if use_mfma else "attn_fwd_simple"
+    name = "attn_fwd_mfma" if _mfma_attn_ok(g, qkv.dtype) else "attn_fwd_simple"
     hip.TIMING.annotate(name, 4.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
     return out, lse
@@ -231,6 +242,12 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
 
 def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None):
     dqkv = torch.empty_like(qkv)
+    if _mfma_attn_ok(g, qkv.dtype):
+        delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
+        hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
+        call("attn_bwd_mfma", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
+             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), dt(qkv))
+        return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
          ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), dt(qkv))
