@@ -44,6 +44,12 @@ int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, in
                   float alpha, int out_mode, int splitk, int dtype_in, int dtype_out, int force_simple,
                   mvuld_stream_t stream);
 
+/* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
+ * layout, fp32 atomic accumulate, contraction split over `splitk` workgroups); dbias[N] += column sums of dY when non-null.
+ * The autograd of every nn.Linear weight/bias on the path (same call sites as mvuld_gemm_nt). */
+int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
+                        float* dbias, int splitk, mvuld_stream_t stream);
+
 /* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
 int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);
 

@@ -265,6 +265,138 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16(GemmArgs g, int tile
     }
 }
 
+// ------------------------------------------------------------------------------------ MFMA bf16, "TN": weight gradients
+// C[N,K] (+)= sum_m A[m,n] * B[m,k]   with A = dY [M,N] and B = X [M,K] in their natural row-major (token-major) layout.
+// Both operands need 8 consecutive m per (n|k) column for the matrix cores, i.e. a transposed fragment: the tiles are
+// staged row-major ([64 m][128 cols], 288-byte rows) and read with ds_read_b64_tr_b16 (4x16 hardware transpose read), using
+// the same k-slot permutation on both sides (slot (g,j<4) <-> m 4g+j, (g,j>=4) <-> m 16+4g+j-4 within a 32-deep step).
+// The contraction (M = tokens, up to 401k) is split over blockIdx.y; partial tiles leave through fp32 atomics.
+typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
+#define TN_BM 64            // contraction depth per LDS tile
+#define TN_LD 144           // elements per LDS row (128 + 16 pad: conflict-free transposed reads)
+#define TN_TILE_BYTES (TN_BM * TN_LD * 2)
+
+__device__ __forceinline__ bf16x8_t tn_read_tr(const bf16* tile, int m0, int col0, int lane) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+    const int fg = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* a0 = tile + (m0 + 4 * fg + q) * TN_LD + col0 + 4 * pp;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)a0);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 16 * TN_LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb,
+                                                            float* __restrict__ C, int64_t ldc, int M, int N, int K, int splitk,
+                                                            float* __restrict__ colsum, int tiles_n, int tiles_k) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int ks = blockIdx.y;
+    const int mtiles = (M + TN_BM - 1) / TN_BM;
+    const int per = (mtiles + splitk - 1) / splitk;
+    const int mt0 = ks * per, mt1 = min(mtiles, mt0 + per);
+    if (mt0 >= mt1) return;
+
+    // staging: 64 rows x 16 chunks (16 B) per operand tile = 1024 chunks, 4 per thread
+    int s_row[4], s_ch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; s_row[i] = c >> 4; s_ch[i] = c & 15; }
+    uint4 ra[4], rb[4];
+    auto stage_load = [&](int mt) {
+        const int m0 = mt * TN_BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + s_row[i];
+            const int ca = n0 + s_ch[i] * 8, cb = k0 + s_ch[i] * 8;
+            ra[i] = (m < M && ca < N) ? *(const uint4*)(A + (int64_t)m * lda + ca) : make_uint4(0, 0, 0, 0);
+            rb[i] = (m < M && cb < K) ? *(const uint4*)(B + (int64_t)m * ldb + cb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        bf16* sa = (bf16*)(smem + buf * 2 * TN_TILE_BYTES);
+        bf16* sb = (bf16*)(smem + buf * 2 * TN_TILE_BYTES + TN_TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint4*)(sa + s_row[i] * TN_LD + s_ch[i] * 8) = ra[i];
+            *(uint4*)(sb + s_row[i] * TN_LD + s_ch[i] * 8) = rb[i];
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;                 // bias gradient: column sums of A (only blocks with tk == 0)
+
+    stage_load(mt0);
+    stage_write(0);
+    __syncthreads();
+    int cur = 0;
+    for (int mt = mt0; mt < mt1; ++mt) {
+        const bool more = (mt + 1) < mt1;
+        if (more) stage_load(mt + 1);
+        const bf16* sa = (const bf16*)(smem + cur * 2 * TN_TILE_BYTES);
+        const bf16* sb = (const bf16*)(smem + cur * 2 * TN_TILE_BYTES + TN_TILE_BYTES);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = tn_read_tr(sa, kk * 32, wr * 64 + i * 16, lane);
+                fb[i] = tn_read_tr(sb, kk * 32, wc * 64 + i * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (colsum && tk == 0 && tid < 128) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int m = 0; m < TN_BM; ++m) s += (float)sa[m * TN_LD + tid];
+            csum += s;
+        }
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (colsum && tk == 0 && tid < 128 && n0 + tid < N) atomicAdd(colsum + n0 + tid, csum);
+    // epilogue: acc[i][j][r] = C[n = n0 + wr*64 + i*16 + 4*fg + r][k = k0 + wc*64 + j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 64 + i * 16 + 4 * fg + r, k = k0 + wc * 64 + j * 16 + fr;
+                if (n < N && k < K) atomicAdd(C + (int64_t)n * ldc + k, acc[i][j][r]);
+            }
+}
+
+// dW[N,K] += dY[M,N]^T . X[M,K]  (fp32 atomic accumulate);  optional db[N] += column sums of dY
+extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
+                                   float* dbias, int splitk, hipStream_t stream) {
+    MV_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0, "gemm_tn_wgrad: bad args");
+    MV_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0,
+                 "gemm_tn_wgrad: operands must be 16-byte aligned with N, K multiples of 8");
+    const int tiles_n = (int)cdiv(N, 128), tiles_k = (int)cdiv(K, 128);
+    const int mtiles = (int)cdiv(M, TN_BM);
+    if (splitk < 1) splitk = 1;
+    if (splitk > mtiles) splitk = mtiles;
+    static bool attr = false;
+    const int lds = 4 * TN_TILE_BYTES;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    dim3 grid(tiles_n * tiles_k, splitk);
+    hipLaunchKernelGGL(gemm_tn_mfma_bf16, grid, dim3(256), lds, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, M, N, K, splitk,
+                       dbias, tiles_n, tiles_k);
+    MV_LAUNCH_CHECK("gemm_tn_wgrad");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                              void* C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,

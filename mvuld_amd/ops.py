@@ -16,6 +16,7 @@ from .hip import call, ptr, dt
 WEIGHT_EPOCH = [0]
 FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU kernel
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
+USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
 
 
 # callbacks fired when the LAST backward of an encoder has run, i.e. all its gradients are final (used to start
@@ -133,6 +134,14 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers."""
     M, N = dy.shape
     K = x.shape[1]
+    if (w_param is not None and dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dyT is None and not FORCE_SIMPLE_GEMM[0]
+            and USE_TN_WGRAD[0]):
+        tiles = math.ceil(N / 128) * math.ceil(K / 128)
+        splitk = max(1, min(math.ceil(M / 64 / 4), 1024 // tiles))
+        hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
+        call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(grad_of(w_param)), K, M, N, K,
+             ptr(grad_of(b_param)) if b_param is not None else None, splitk)
+        return
     if b_param is not None:
         colsum_into(dy, grad_of(b_param))
     if w_param is None:

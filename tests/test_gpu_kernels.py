@@ -398,3 +398,18 @@ def test_embed_im2col_patchmerge_dropout(gpu, dtype):
     d1, d2 = ops.dropout(big, 0.2, 1234), ops.dropout(big, 0.2, 1234)
     assert torch.equal(d1, d2) and abs(float((d1 == 0).float().mean()) - 0.2) < 0.01
     assert abs(float(d1.float().mean()) - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (1000, 384, 136), (777, 72, 200), (20000, 256, 512)])
+def test_gemm_tn_wgrad(gpu, M, N, K):
+    """dW += dY^T X and db += colsum(dY) through the transpose-free matrix-core kernel (bf16 operands)."""
+    from mvuld_amd import ops
+    dy, x = rt(T("tn_dy", (M, N)), torch.bfloat16), rt(T("tn_x", (M, K)), torch.bfloat16)
+    w = torch.nn.Parameter(torch.zeros(N, K, device=gpu))
+    b = torch.nn.Parameter(torch.zeros(N, device=gpu))
+    w.grad = torch.ones(N, K, device=gpu)
+    b.grad = torch.ones(N, device=gpu)
+    gdy, gx = dev(dy, torch.bfloat16), dev(x, torch.bfloat16)
+    ops.linear_wgrad(gdy, gx, w, b)
+    assert rel(w.grad, dy.t() @ x + 1.0) < 2e-3
+    assert rel(b.grad, dy.sum(0) + 1.0) < 2e-3
