@@ -12,6 +12,7 @@
 //   RoBERTa q/k/v/out/intermediate/output dense, GATConv fc, head Linear layers
 //   (GraphModel.py:153-209) and Rs_GCN's 1x1 convs + theta^T.phi / R.g (Rs_GCN.py:57-70).
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6 };
 enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_ATOMIC = 2 };
@@ -108,17 +109,19 @@ typedef float __attribute__((ext_vector_type(4))) f32x4_t;
 #define GT_BM 128
 #define GT_BN 128
 #define GT_BK 64
-#define GT_LDS_MAIN (2 * 2 * GT_BM * GT_BK * 2)       // 64 KiB: {A,B} x 2 buffers
 #define GT_EPI_LD 68
-#define GT_LDS_EPI (4 * 64 * GT_EPI_LD * 4)           // 69632 B: per-wave 64x64 fp32 staging
-#define GT_LDS_BYTES (GT_LDS_EPI > GT_LDS_MAIN ? GT_LDS_EPI : GT_LDS_MAIN)
+// LDS: NBUF x {A,B} tiles of 16 KiB, and the epilogue's per-wave fp32 staging done in 2/NBUF... passes:
+//   NBUF = 2: 64 KiB main, 4 x 64 x 68 x 4 = 69632 B epilogue  -> 2 workgroups / CU
+//   NBUF = 1: 32 KiB main, epilogue in two 32-row halves (34816 B) -> 3 workgroups / CU (VGPR-limited): more tiles in
+//             flight per CU, which is what the short-K shapes of this model need (the loop is L2-latency bound)
+#define GT_LDS_BYTES_N(NBUF) ((NBUF) == 2 ? 69632 : 34816)
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [128][64] bf16 tile
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16(GemmArgs g, int tiles_m, int tiles_n) {
+template <typename TO, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -186,12 +189,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16(GemmArgs g, int tile
 
     if (kt0 < kt1) {
         stage_load(kt0);
-        stage_write(0);
+        if (NBUF == 2) stage_write(0);
     }
-    __syncthreads();
+    if (NBUF == 2) __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1) < kt1;
+        if (NBUF == 1) {
+            __syncthreads();                 // every wave is done reading the previous tile
+            stage_write(0);
+            __syncthreads();
+        }
         if (more) stage_load(kt + 1);
         const char* sa = smem + cur * 32768;
         const char* sb = sa + 16384;
@@ -209,60 +217,98 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_bf16(GemmArgs g, int tile
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) stage_write(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NBUF == 2) {
+            if (more) stage_write(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
-    // ---- epilogue: accumulators -> per-wave LDS tile -> row-major 16-byte-per-lane pass
-    float* ep = (float*)(smem + wave * (64 * GT_EPI_LD * 4));
+    // ---- epilogue: accumulators -> per-wave LDS tile -> row-major 16-byte-per-lane pass  (EPH halves of 64/EPH rows)
+    constexpr int EPH = NBUF == 2 ? 1 : 2;
+    constexpr int EROWS = 64 / EPH;
+    float* ep = (float*)(smem + wave * (EROWS * GT_EPI_LD * 4));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int half = 0; half < EPH; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4 / EPH; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[half * (4 / EPH) + i][j][r];
     __syncthreads();
-    const bool vec_ok = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.out_mode == OUT_STORE) &&
-                        (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_ELU || g.epi == EPI_GELU) &&
-                        (g.ldaux % 4 == 0);
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-        const int lr = p * 4 + fg, lc = fr * 4;
-        const int row = m0 + wr * 64 + lr, col = n0 + wc * 64 + lc;
-        if (row >= g.M || col >= g.N) continue;
-        const float4 v4 = *(const float4*)(ep + lr * GT_EPI_LD + lc);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        if (vec_ok) {
-            float pre[4];
+    // row-major pass: 8 lanes x 8 columns cover a 64-wide row, 8 rows per pass, 16-byte (bf16) / 32-byte (f32) stores
+    const int lc = (lane & 7) * 8;
+    const int col = n0 + wc * 64 + lc;
+    const bool vec_ok = (g.out_mode == OUT_STORE) && (g.N % 8 == 0) && (g.ldc % 8 == 0) && (g.epi < EPI_GELU || (g.ldaux % 8 == 0));
+    float bias8[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = g.alpha * v[e];
-                if (g.bias) x += g.bias[col + e];
+    for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+#pragma unroll 2
+    for (int p = 0; p < 8 / EPH; ++p) {
+        const int lr = p * 8 + (lane >> 3);
+        const int row = m0 + wr * 64 + half * EROWS + lr;
+        if (row >= g.M || col >= g.N) continue;
+        const float4 va = *(const float4*)(ep + lr * GT_EPI_LD + lc);
+        const float4 vb = *(const float4*)(ep + lr * GT_EPI_LD + lc + 4);
+        float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        if (vec_ok) {
+            float ax[8];
+            if (g.epi >= EPI_MUL_DGELU) {
+                const TO* ap = aux + (int64_t)row * g.ldaux + col;
+                if constexpr (sizeof(TO) == 4) {
+                    const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
+                    ax[0] = a0.x; ax[1] = a0.y; ax[2] = a0.z; ax[3] = a0.w; ax[4] = a1.x; ax[5] = a1.y; ax[6] = a1.z; ax[7] = a1.w;
+                } else {
+                    const bf16x8 a = *(const bf16x8*)ap;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ax[e] = (float)a.v[e];
+                }
+            }
+            float pre[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = g.alpha * v[e] + bias8[e];
                 pre[e] = x;
-                if (g.epi == EPI_GELU) x = gelu_erf(x);
-                else if (g.epi == EPI_ELU) x = elu1(x);
+                switch (g.epi) {
+                    case EPI_GELU: x = gelu_erf(x); break;
+                    case EPI_ELU: x = elu1(x); break;
+                    case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                    case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
+                    case EPI_ADD_AUX: x += ax[e]; break;
+                    default: break;
+                }
                 v[e] = x;
             }
             TO* cp = C + (int64_t)row * g.ldc + col;
             if constexpr (sizeof(TO) == 4) {
                 *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-                if (g.epi == EPI_GELU && aux)
-                    *(float4*)(aux + (int64_t)row * g.ldaux + col) = make_float4(pre[0], pre[1], pre[2], pre[3]);
-            } else {
-                bf16x4 o; o.v[0] = (bf16)v[0]; o.v[1] = (bf16)v[1]; o.v[2] = (bf16)v[2]; o.v[3] = (bf16)v[3];
-                *(bf16x4*)cp = o;
+                *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 if (g.epi == EPI_GELU && aux) {
-                    bf16x4 q; q.v[0] = (bf16)pre[0]; q.v[1] = (bf16)pre[1]; q.v[2] = (bf16)pre[2]; q.v[3] = (bf16)pre[3];
-                    *(bf16x4*)(aux + (int64_t)row * g.ldaux + col) = q;
+                    float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
+                    *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
+                    *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+                }
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
+                *(bf16x8*)cp = o;
+                if (g.epi == EPI_GELU && aux) {
+                    bf16x8 q;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
+                    *(bf16x8*)(aux + (int64_t)row * g.ldaux + col) = q;
                 }
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 8; ++e)
                 if (col + e < g.N) epilogue_store<TO>(g, C, aux, row, col + e, v[e]);
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------ MFMA bf16, "TN": weight gradients
@@ -423,14 +469,20 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
     if (use_mfma) {
         const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(N, GT_BN);
         dim3 grid(tiles_m * tiles_n, batch * splitk);
-        if (dtype_out == MVULD_F32) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES); attr = true; }
-            hipLaunchKernelGGL(gemm_nt_mfma_bf16<float>, grid, dim3(256), GT_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        static int variant = -1;             // MVULD_GEMM_NBUF=1|2 selects the LDS pipelining variant (default 1)
+        if (variant < 0) { const char* e = getenv("MVULD_GEMM_NBUF"); variant = (e && e[0] == '2') ? 2 : 1; }
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
+            (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
+            attr = true;
+        }
+        if (variant == 2) {
+            if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16<float, 2>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((gemm_nt_mfma_bf16<bf16, 2>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
         } else {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES); attr = true; }
-            hipLaunchKernelGGL(gemm_nt_mfma_bf16<bf16>, grid, dim3(256), GT_LDS_BYTES, stream, g, tiles_m, tiles_n);
+            if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16<float, 1>), grid, dim3(256), GT_LDS_BYTES_N(1), stream, g, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((gemm_nt_mfma_bf16<bf16, 1>), grid, dim3(256), GT_LDS_BYTES_N(1), stream, g, tiles_m, tiles_n);
         }
         MV_LAUNCH_CHECK("gemm_nt_mfma_bf16");
         return 0;

