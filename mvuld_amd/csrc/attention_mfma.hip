@@ -17,6 +17,7 @@
 // in backward from the saved log-sum-exp; delta = rowsum(dO * O) comes from a small pre-kernel.  d(bias table) is
 // accumulated with LDS float atomics per workgroup and flushed with one global atomic per touched entry.
 #include "common.h"
+#include <stdlib.h>
 
 struct AttnGeom {
     int mode, B, H, N, nW, res, ws, shift;
@@ -122,9 +123,80 @@ __device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int ld, int d0, int 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Scores live in log2 units (log2(e) is folded into q~, the bias table and the mask constants) so the softmax uses bare
+// v_exp_f32.  Per-key info word (Kinfo): MODE 0: 4*(iy*(2w-1)+ix) | region << 16 (| AM_PAD), MODE 1: valid (| AM_PAD).
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// log2-domain score fix-up of one element.  tabq = (char*)tab + 4*bq  (MODE 0)
+template <int MODE, bool MASK, bool TAIL>
+__device__ __forceinline__ float am_fix(float s, int ki, const char* tabq, int regq, int vq) {
+    float v;
+    if (MODE == 0) {
+        const int off = (MASK || TAIL) ? (ki & 0xffff) : ki;
+        v = s + *(const float*)(tabq - off);
+        if (MASK) v = (((ki >> 16) & 0xff) != regq) ? v - 100.0f * LOG2E : v;
+    } else {
+        v = (vq & ki & 1) ? s : s - 10000.0f * LOG2E;
+    }
+    if (TAIL) v = (ki & AM_PAD) ? NEG_BIG : v;
+    return v;
+}
+
+// one block of NT 16-key tiles (NT = 4: 64 keys, NT = 2: 32 keys) of the online-softmax forward
+template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+__device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
+                                             const bf16x8_t (&qf)[HD / 32], const char* tabq, int regq, int vq, int lane, float& m,
+                                             float& l, f32x4_t (&oacc)[HD / 16]) {
+    constexpr int KLD = HD + 8;
+    const int fc = lane & 15, fg = lane >> 4;
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks)
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8), qf[ks], s[t], 0, 0, 0);
+    }
+    float sv[NT][4];
+    float bm = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
+        const int ki[4] = {inf.x, inf.y, inf.z, inf.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sv[t][r] = am_fix<MODE, MASK, TAIL>(s[t][r], ki[r], tabq, regq, vq);
+            bm = fmaxf(bm, sv[t][r]);
+        }
+    }
+    bm = max4g(bm);
+    const float mn = fmaxf(m, bm);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    float ps = 0.f;
+    bf16x8_t pb[NT / 2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(sv[t][r] - mn);
+            ps += p;
+            pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+        }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d) {
+        oacc[d] *= alpha;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr)
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Vs, KLD, d * 16, kb + 32 * pr, lane), pb[pr], oacc[d], 0, 0, 0);
+    }
+}
+
 // grid.x = B*nW*H*qsplit: workgroup (bwh, part) stages K,V of (window, head) once and walks the q tiles  part, part+qsplit, ...
-template <int HD, int MODE>
-__global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+template <int HD, int MODE, bool MASK>
+__global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                        const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                        bf16* __restrict__ out, float* __restrict__ lse, int Npad, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,7 +204,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* _
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]  (normalised for MODE 0)
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
-    float* tab = (float*)(Kinfo + Npad);          // MODE 0: [(2ws-1)^2]
+    float* tab = (float*)(Kinfo + Npad);          // MODE 0: [(2ws-1)^2], in log2 units
     const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
@@ -141,25 +213,30 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* _
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Kinfo[i] = am_info(g, valid, b, w, i);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        const int inf = am_info(g, valid, b, w, i);
+        Kinfo[i] = MODE == 0 ? (((inf & 0xffff) << 2) | (inf & ~0xffff)) : inf;
+    }
     int C0 = 0;
     float tau = 1.f;
     if (MODE == 0) {
         const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
-        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
         C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
         tau = __expf(fminf(logit_scale[h], LN100));
     }
     __syncthreads();
 
     const int ntile = (g.N + 15) / 16;
-    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * 8) {
+    const int nfull64 = (g.N / 64) * 64;          // keys covered by pad-free 64-key blocks
+    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
         const int nq = qt * 16 + fc;
         const bool qok = nq < g.N;
         const int nqc = qok ? nq : g.N - 1;
         const int64_t tq = am_token(g, b, w, nqc);
         const int qinf = am_info(g, valid, b, w, nqc);
-        const int bq = (qinf & 0xffff) + C0, regq = (qinf >> 16) & 0xff;
+        const char* tabq = (const char*)tab + 4 * ((qinf & 0xffff) + C0);
+        const int regq = (qinf >> 16) & 0xff, vq = qinf;
         bf16x8_t qf[HD / 32];
         {
             float f[HD / 32][8];
@@ -171,8 +248,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
             }
-            float sc = g.scale;
-            if (MODE == 0) sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+            float sc = g.scale * LOG2E;
+            if (MODE == 0) sc = tau * LOG2E / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
 #pragma unroll
@@ -182,52 +259,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* _
         f32x4_t oacc[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        for (int kb = 0; kb < Npad; kb += 32) {
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
-                const bf16x8_t a0 = *(const bf16x8_t*)(Ks + (kb + fc) * KLD + ks * 32 + fg * 8);
-                const bf16x8_t a1 = *(const bf16x8_t*)(Ks + (kb + 16 + fc) * KLD + ks * 32 + fg * 8);
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[ks], s1, 0, 0, 0);
-            }
-            const int4 i0 = *(const int4*)(Kinfo + kb + 4 * fg);
-            const int4 i1 = *(const int4*)(Kinfo + kb + 16 + 4 * fg);
-            const int ki[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-            float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            float bm = NEG_BIG;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float v = s[r];
-                if (MODE == 0) {
-                    v += tab[bq - (ki[r] & 0xffff)];
-                    v = (((ki[r] >> 16) & 0xff) != regq) ? v - 100.0f : v;
-                } else {
-                    v = (qinf & ki[r] & 1) ? v : v - 10000.0f;
-                }
-                s[r] = (ki[r] & AM_PAD) ? NEG_BIG : v;
-                bm = fmaxf(bm, s[r]);
-            }
-            bm = max4g(bm);
-            const float mn = fmaxf(m, bm);
-            const float alpha = __expf(m - mn);
-            bf16x8_t pb;
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float p = __expf(s[r] - mn);
-                ps += p;
-                pb[r] = (bf16)p;
-            }
-            l = l * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d) {
-                oacc[d] *= alpha;
-                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Vs, KLD, d * 16, kb, lane), pb, oacc[d], 0, 0, 0);
-            }
-            m = mn;
-        }
+        int kb = 0;
+        for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
+        for (; kb < Npad; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
         l = sum4g(l);
         if (qok) {
             const float inv = 1.0f / l;
@@ -238,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(AttnGeom g, const bf16* _
                 for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(oacc[d][r] * inv);
                 *(uint2*)(out + tq * C + h * HD + d * 16 + 4 * fg) = o.u;
             }
-            if (fg == 0) lse[((int64_t)bw * g.H + h) * g.N + nq] = m + __logf(l);
+            if (fg == 0) lse[((int64_t)bw * g.H + h) * g.N + nq] = (m + __log2f(l)) * LN2;
         }
     }
 }
@@ -262,7 +296,7 @@ __global__ void attn_delta_k(const bf16* __restrict__ out, const bf16* __restric
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d table, d logit_scale)
 template <int HD, int MODE>
-__global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+__global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                           const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -272,8 +306,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
-    float* red = (float*)(Kinfo + Npad);          // [8]
-    float* tab = red + 8;                         // MODE 0: [T2]
+    float* red = (float*)(Kinfo + Npad);          // [16]
+    float* tab = red + 16;                        // MODE 0: [T2]
     const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
     const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16
 
     float dtau_part = 0.f;
     const int ntile = (g.N + 15) / 16;
-    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * 8) {
+    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
         const int nq = qt * 16 + fc;
         const bool qok = nq < g.N;
         const int nqc = qok ? nq : g.N - 1;
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16
         __syncthreads();
         if (threadIdx.x == 0 && logit_scale[h] < LN100) {
             float t = 0.f;
-            for (int i = 0; i < 8; ++i) t += red[i];
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
             atomicAdd(dlogit_scale + h, t * tau);
         }
     }
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16
 // one row, a key block = one row padded to 32 slots), a wave owns one (dy, q-part) and sweeps yq with yk = yq - dy, so dS is
 // summed in 8 registers per lane and only the final sums touch LDS / global atomics (~14x fewer atomics at w = 28).
 template <int HD>
-__global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+__global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                              const float* __restrict__ logit_scale, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              float* __restrict__ dtable16, int Npad, int split) {
@@ -448,7 +482,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const b
     const int qw = (ws + nqp - 1) / nqp;          // tokens per q part (<= 16)
     const int nitem = W2 * nqp;                   // (dy, q part)
     // key slots of this lane: tile t, row 4*fg + r  ->  xk = 16 t + 4 fg + r
-    for (int item = part + split * wave; item < nitem; item += split * 8) {
+    for (int item = part + split * wave; item < nitem; item += split * (blockDim.x >> 6)) {
         const int dy = item / nqp - (ws - 1), qp = item % nqp;
         const int xq = qp * qw + fc;
         const bool qv = fc < qw && xq < ws;
@@ -534,7 +568,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const b
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int HD, int MODE>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+__global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                            const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv, int Npad, int ksplit) {
@@ -575,7 +609,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf1
     __syncthreads();
 
     const int ntile = (g.N + 15) / 16;
-    for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * 8) {
+    for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * (blockDim.x >> 6)) {
         const int nk = kt * 16 + fc;
         const bool kok = nk < g.N;
         const int nkc = kok ? nk : g.N - 1;
@@ -726,7 +760,7 @@ static int am_split(int64_t groups, int ntile) {
 #define AM_LAUNCH(KERNEL, HDV, MODEV, bytes, ...)                                                \
     do {                                                                                          \
         if (am_set_lds(KERNEL<HDV, MODEV>, bytes, #KERNEL)) return 1;                             \
-        hipLaunchKernelGGL((KERNEL<HDV, MODEV>), grid, dim3(512), bytes, stream, __VA_ARGS__);    \
+        hipLaunchKernelGGL((KERNEL<HDV, MODEV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes, stream, __VA_ARGS__);    \
     } while (0)
 
 #define AM_DISPATCH(KERNEL, bytes, ...)                                      \
@@ -749,7 +783,19 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
     const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)T2 * 4;
     const int qsplit = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * qsplit);
-    AM_DISPATCH(attn_fwd_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (bf16*)out, lse, Npad, qsplit);
+    // 16 waves (4 per SIMD) hide the LDS / MFMA latencies of the score loop twice as well as 8; MVULD_ATTN_FWD_THREADS overrides
+    static int fwd_threads = 0;
+    if (!fwd_threads) { const char* e = getenv("MVULD_ATTN_FWD_THREADS"); fwd_threads = e ? atoi(e) : 1024; }
+#define AM_FWD(HDV, MODEV, MASKV)                                                                              \
+    do {                                                                                                        \
+        if (am_set_lds(attn_fwd_mfma_k<HDV, MODEV, MASKV>, bytes, "attn_fwd_mfma_k")) return 1;                 \
+        hipLaunchKernelGGL((attn_fwd_mfma_k<HDV, MODEV, MASKV>), grid, dim3(fwd_threads), bytes, stream, g, (const bf16*)qkv, table16, \
+                           logit_scale, valid, (bf16*)out, lse, Npad, qsplit);                                  \
+    } while (0)
+    if (mode == 0 && hd == 32) { if (shift > 0) AM_FWD(32, 0, true); else AM_FWD(32, 0, false); }
+    else if (mode == 0) { if (shift > 0) AM_FWD(64, 0, true); else AM_FWD(64, 0, false); }
+    else if (hd == 32) AM_FWD(32, 1, false);
+    else AM_FWD(64, 1, false);
     MV_LAUNCH_CHECK("attn_fwd_mfma");
     return 0;
 }
@@ -772,7 +818,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);
     {
-        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 32 + (size_t)T2 * 4;
+        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
         AM_DISPATCH(attn_bwd_dq_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta,
                     (bf16*)dqkv, dtable16, dlogit_scale, Npad, split);
     }
@@ -788,7 +834,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         int sp = 1;
         while ((int64_t)B * nW * H * sp < 1024 && sp * 2 * 8 <= items) sp *= 2;
         if (am_set_lds(attn_bwd_dbias_mfma_k<32>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv, table16,
+        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv, table16,
                            logit_scale, (const bf16*)dout, lse, ws_delta, dtable16, Npad, sp);
     }
     MV_LAUNCH_CHECK("attn_bwd_mfma");
