@@ -294,20 +294,58 @@ __global__ void attn_delta_k(const bf16* __restrict__ out, const bf16* __restric
     delta[i] = s;
 }
 
-// ------------------------------------------------------------------------------------------------ backward: dQ (+ d table, d logit_scale)
-template <int HD, int MODE>
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
+// one block of NT key tiles: dS^T = P^T o (dP^T - delta), dQ^T += K^T . dS^T   (scores in log2 units, gradients in natural units)
+template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+__device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
+                                            const bf16x8_t (&qf)[HD / 32], const bf16x8_t (&dof)[HD / 32], const char* tabq, int regq, int vq,
+                                            float L2q, float Dq, int lane, f32x4_t (&dq)[HD / 16]) {
+    constexpr int KLD = HD + 8;
+    const int fc = lane & 15, fg = lane >> 4;
+    f32x4_t s[NT], dp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dp[t] = s[t];
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            const int o = (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o), qf[ks], s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o), dof[ks], dp[t], 0, 0, 0);
+        }
+    }
+    bf16x8_t dsb[NT / 2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
+        const int ki[4] = {inf.x, inf.y, inf.z, inf.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sv = am_fix<MODE, MASK, TAIL>(s[t][r], ki[r], tabq, regq, vq);      // padding keys -> NEG_BIG -> p = 0
+            const float ds = __builtin_amdgcn_exp2f(sv - L2q) * (dp[t][r] - Dq);
+            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)ds;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d)
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr)
+            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ks, KLD, d * 16, kb + 32 * pr, lane), dsb[pr], dq[d], 0, 0, 0);
+}
+
+template <int HD, int MODE, bool MASK>
 __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                           const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                          float* __restrict__ dtable16, float* __restrict__ dlogit_scale, int Npad, int qsplit) {
+                                                          float* __restrict__ dlogit_scale, bf16* __restrict__ qt_out, int Npad, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KLD = HD + 8;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
     float* red = (float*)(Kinfo + Npad);          // [16]
-    float* tab = red + 16;                        // MODE 0: [T2]
+    float* tab = red + 16;                        // MODE 0: [T2], log2 units
     const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
     const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
@@ -317,11 +355,14 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Kinfo[i] = am_info(g, valid, b, w, i);
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        const int inf = am_info(g, valid, b, w, i);
+        Kinfo[i] = MODE == 0 ? (((inf & 0xffff) << 2) | (inf & ~0xffff)) : inf;
+    }
     int C0 = 0;
     float tau = 1.f;
     if (MODE == 0) {
-        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
         C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
         tau = __expf(fminf(logit_scale[h], LN100));
     }
@@ -329,13 +370,15 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
 
     float dtau_part = 0.f;
     const int ntile = (g.N + 15) / 16;
+    const int nfull64 = (g.N / 64) * 64;
     for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
         const int nq = qt * 16 + fc;
         const bool qok = nq < g.N;
         const int nqc = qok ? nq : g.N - 1;
         const int64_t tq = am_token(g, b, w, nqc);
         const int qinf = am_info(g, valid, b, w, nqc);
-        const int bq = (qinf & 0xffff) + C0, regq = (qinf >> 16) & 0xff;
+        const char* tabq = (const char*)tab + 4 * ((qinf & 0xffff) + C0);
+        const int regq = (qinf >> 16) & 0xff, vq = qinf;
         bf16x8_t qf[HD / 32], dof[HD / 32];
         {
             float f[HD / 32][8];
@@ -349,53 +392,26 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
             }
-            float sc = g.scale;
-            if (MODE == 0) sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+            float sc = g.scale * LOG2E;
+            if (MODE == 0) sc = tau * LOG2E / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)(f[ks][e] * sc);
+            if (MODE == 0 && qt_out && qok) {          // q~ * log2(e), re-used by the bias-table gradient pass
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) { U8 o; o.v = qf[ks]; *(uint4*)(qt_out + tq * C + h * HD + ks * 32 + fg * 8) = o.u; }
+            }
         }
-        const float Lq = lse[((int64_t)bw * g.H + h) * g.N + nqc];
-        const float Dq = qok ? delta[tq * g.H + h] : 0.f;
+        const float L2q = lse[((int64_t)bw * g.H + h) * g.N + nqc] * LOG2E;
+        const float Dq = qok ? delta[tq * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
         f32x4_t dq[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        for (int kb = 0; kb < Npad; kb += 32) {
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-#pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
-                const int o0 = (kb + fc) * KLD + ks * 32 + fg * 8, o1 = (kb + 16 + fc) * KLD + ks * 32 + fg * 8;
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o0), qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o1), qf[ks], s1, 0, 0, 0);
-                p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o0), dof[ks], p0, 0, 0, 0);
-                p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o1), dof[ks], p1, 0, 0, 0);
-            }
-            const int4 i0 = *(const int4*)(Kinfo + kb + 4 * fg);
-            const int4 i1 = *(const int4*)(Kinfo + kb + 16 + 4 * fg);
-            const int ki[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-            bf16x8_t dsb;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float sv = s[r];
-                if (MODE == 0) {
-                    sv += tab[bq - (ki[r] & 0xffff)];
-                    sv = (((ki[r] >> 16) & 0xff) != regq) ? sv - 100.0f : sv;
-                } else {
-                    sv = (qinf & ki[r] & 1) ? sv : sv - 10000.0f;
-                }
-                // padding keys contribute nothing; padding queries have dO = 0 and delta = 0, hence ds = 0
-                const float ds = (ki[r] & AM_PAD) ? 0.f : __expf(sv - Lq) * (dp[r] - Dq);
-                dsb[r] = (bf16)ds;
-            }
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d)
-                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ks, KLD, d * 16, kb, lane), dsb, dq[d], 0, 0, 0);
-        }
-        // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]
+        int kb = 0;
+        for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
+        for (; kb < Npad; kb += 32) am_dq_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
+        // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
         if (MODE == 0) {
             float qh[HD / 16][4];
             float ss = 0.f;
@@ -452,16 +468,16 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
 // one row, a key block = one row padded to 32 slots), a wave owns one (dy, q-part) and sweeps yq with yk = yq - dy, so dS is
 // summed in 8 registers per lane and only the final sums touch LDS / global atomics (~14x fewer atomics at w = 28).
 template <int HD>
-__global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
-                                                             const float* __restrict__ logit_scale, const bf16* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             float* __restrict__ dtable16, int Npad, int split) {
+__global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
+                                                              const float* __restrict__ table16, const bf16* __restrict__ dout,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              float* __restrict__ dtable16, int Npad, int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KLD = HD + 8;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD] normalised keys
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Ktok = (int*)(Vs + (size_t)Npad * KLD);  // [Npad] token index of every window position
-    float* tab = (float*)(Ktok + Npad);           // [T2]
+    float* tab = (float*)(Ktok + Npad);           // [T2]  log2 units
     const int W2 = 2 * g.ws - 1, T2 = W2 * W2;
     float* dtab = tab + T2;                       // [T2]
     const int part = blockIdx.x % split, bwh = blockIdx.x / split;
@@ -474,13 +490,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) Ktok[i] = (int)am_token(g, b, w, min(i, g.N - 1));
-    for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = table16[(int64_t)i * g.H + h]; dtab[i] = 0.f; }
-    const float tau = __expf(fminf(logit_scale[h], LN100));
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = table16[(int64_t)i * g.H + h] * LOG2E; dtab[i] = 0.f; }
     __syncthreads();
 
     const int nqp = (ws + 15) / 16;               // q parts per image row
     const int qw = (ws + nqp - 1) / nqp;          // tokens per q part (<= 16)
     const int nitem = W2 * nqp;                   // (dy, q part)
+    const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
     // key slots of this lane: tile t, row 4*fg + r  ->  xk = 16 t + 4 fg + r
     for (int item = part + split * wave; item < nitem; item += split * (blockDim.x >> 6)) {
         const int dy = item / nqp - (ws - 1), qp = item % nqp;
@@ -493,64 +509,58 @@ __global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const 
         // Everything that depends only on (lane, register) is hoisted out of the row sweep: the table entry (hence the
         // bias value) and the x-part of the shift-mask region test.  The y-part of the region test is wave-uniform.
         const int xqc = min(xq, ws - 1);
-        const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
         const int rxq = g.shift > 0 ? am_rid(g, wx * ws + xqc) : 0;
+        // bias[r] also carries the x-part of the shift mask (-100) and, for slots beyond the row (padding), -inf.
+        // (A pair that differs in both the x and the y region gets -200 instead of the reference's -100: both underflow
+        //  exp() to exactly 0 in fp32 against scores bounded by tau + 16.)
         float bias[8];
-        bool xdiff[8], kval[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
             const int xkc = min(xk, ws - 1);
             bias[r] = tab[(dy + ws - 1) * W2 + (xqc - xkc + ws - 1)];
-            xdiff[r] = g.shift > 0 && am_rid(g, wx * ws + xkc) != rxq;
-            kval[r] = xk < ws;
+            if (g.shift > 0 && am_rid(g, wx * ws + xkc) != rxq) bias[r] -= 100.0f * LOG2E;
+            if (xk >= ws) bias[r] = NEG_BIG;
         }
-        // software pipeline: the q-side operands of row yq+1 are fetched from global while row yq is being processed
-        U8 nx, ny;
-        float nL = 0.f, nD = 0.f;
-        auto fetch = [&](int yq) {
+        const int ka0 = min(fc, ws - 1), ka1 = min(16 + fc, ws - 1);      // A rows: key slot (t, fc) of image row yk
+        // q-side operands of one image row: q~*log2e (from the dQ pass), dO, lse*log2e, delta
+        struct QRow { U8 q, d; float L2, D; };
+        auto fetch = [&](int yq, QRow& o) {
             const int nq = yq * ws + xqc;
             const int64_t tq = Ktok[nq];
-            nx.u = *(const uint4*)(qkv + tq * rs + h * HD + fg * 8);
-            ny.u = qv ? *(const uint4*)(dout + tq * C + h * HD + fg * 8) : make_uint4(0, 0, 0, 0);
-            nL = lse[((int64_t)bw * g.H + h) * g.N + nq];
-            nD = qv ? delta[tq * g.H + h] : 0.f;
+            o.q.u = *(const uint4*)(qt + tq * C + h * HD + fg * 8);
+            o.d.u = qv ? *(const uint4*)(dout + tq * C + h * HD + fg * 8) : make_uint4(0, 0, 0, 0);
+            o.L2 = lse[((int64_t)bw * g.H + h) * g.N + nq] * LOG2E;
+            o.D = qv ? delta[tq * g.H + h] : 0.f;
         };
-        if (y0 < y1) fetch(y0);
-        for (int yq = y0; yq < y1; ++yq) {
+        auto row = [&](int yq, const QRow& o) {
             const int yk = yq - dy;
-            const U8 x = nx;
-            const bf16x8_t dof = ny.v;
-            const float Lq = nL, Dq = nD;
-            if (yq + 1 < y1) fetch(yq + 1);
             const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yq) != am_rid(g, wy * ws + yk);     // wave-uniform
-            bf16x8_t qf;
-            {
-                float f[8];
-                float ss = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { f[e] = (float)x.e[e]; ss += f[e] * f[e]; }
-                const float sc = tau / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[e] = (bf16)(f[e] * sc);
-            }
-            // A rows: key slot (t, fc) -> token yk*ws + min(16 t + fc, ws-1)
-            const int k0 = yk * ws + min(fc, ws - 1), k1 = yk * ws + min(16 + fc, ws - 1);
+            const int k0 = (yk * ws + ka0) * KLD + fg * 8, k1 = (yk * ws + ka1) * KLD + fg * 8;
             f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k0 * KLD + fg * 8), qf, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k1 * KLD + fg * 8), qf, s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k0 * KLD + fg * 8), dof, p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k1 * KLD + fg * 8), dof, p1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k0), o.q.v, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k1), o.q.v, s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k0), o.d.v, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k1), o.d.v, p1, 0, 0, 0);
             const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
             const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            const float c2 = (ydiff ? -100.0f * LOG2E : 0.f) - o.L2;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float sv = s[r] + bias[r];
-                sv = (ydiff || xdiff[r]) ? sv - 100.0f : sv;
-                const float ds = __expf(sv - Lq) * (dp[r] - Dq);
-                acc[r] += kval[r] ? ds : 0.f;
-            }
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(__builtin_amdgcn_exp2f(s[r] + bias[r] + c2), dp[r] - o.D, acc[r]);
+        };
+        // two rows per trip, the next pair in flight while this pair is multiplied
+        QRow a, c, na, nc;
+        int yq = y0;
+        if (yq < y1) fetch(yq, na);
+        if (yq + 1 < y1) fetch(yq + 1, nc);
+        for (; yq + 1 < y1; yq += 2) {
+            a = na; c = nc;
+            if (yq + 2 < y1) fetch(yq + 2, na);
+            if (yq + 3 < y1) fetch(yq + 3, nc);
+            row(yq, a);
+            row(yq + 1, c);
         }
+        if (yq < y1) row(yq, na);
         if (qv) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -567,19 +577,79 @@ __global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int HD, int MODE>
+// per-query info word Qi: MODE 0: 4*(iy*(2w-1)+ix + C0) | region << 16 (| AM_PAD); MODE 1: valid (| AM_PAD).  tabk = (char*)tab - 4*bk.
+template <int MODE, bool MASK, bool TAIL>
+__device__ __forceinline__ float am_fix_k(float s, int qi, const char* tabk, int regk, int vk) {
+    float v;
+    if (MODE == 0) {
+        const int off = (MASK || TAIL) ? (qi & 0xffff) : qi;
+        v = s + *(const float*)(tabk + off);
+        if (MASK) v = (((qi >> 16) & 0xff) != regk) ? v - 100.0f * LOG2E : v;
+    } else {
+        v = (vk & qi & 1) ? s : s - 10000.0f * LOG2E;
+    }
+    if (TAIL) v = (qi & AM_PAD) ? NEG_BIG : v;
+    return v;
+}
+
+template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+__device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const bf16* __restrict__ Ds, const int* __restrict__ Qi,
+                                             const float* __restrict__ Ql, const float* __restrict__ Qd, int qb, const bf16x8_t (&kf)[HD / 32],
+                                             const bf16x8_t (&vf)[HD / 32], const char* tabk, int regk, int vk, int lane,
+                                             f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16]) {
+    constexpr int KLD = HD + 8;
+    const int fc = lane & 15, fg = lane >> 4;
+    f32x4_t s[NT], dp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dp[t] = s[t];
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            const int o = (qb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o), kf[ks], s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o), vf[ks], dp[t], 0, 0, 0);
+        }
+    }
+    bf16x8_t pb[NT / 2], dsb[NT / 2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int4 inf = *(const int4*)(Qi + qb + 16 * t + 4 * fg);
+        const float4 l4 = *(const float4*)(Ql + qb + 16 * t + 4 * fg);
+        const float4 d4 = *(const float4*)(Qd + qb + 16 * t + 4 * fg);
+        const int qi[4] = {inf.x, inf.y, inf.z, inf.w};
+        const float L[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float D[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sv = am_fix_k<MODE, MASK, TAIL>(s[t][r], qi[r], tabk, regk, vk);
+            const float p = __builtin_amdgcn_exp2f(sv - L[r]);                 // padding queries -> NEG_BIG -> 0
+            pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * (dp[t][r] - D[r]));
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD / 16; ++d)
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ds, KLD, d * 16, qb + 32 * pr, lane), pb[pr], dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Qs, KLD, d * 16, qb + 32 * pr, lane), dsb[pr], dk[d], 0, 0, 0);
+        }
+}
+
+template <int HD, int MODE, bool MASK>
 __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                            const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv, int Npad, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KLD = HD + 8;
-    bf16* Qs = (bf16*)smem;                       // [Npad][KLD]   q~
+    bf16* Qs = (bf16*)smem;                       // [Npad][KLD]   q~ * log2(e)
     bf16* Ds = Qs + (size_t)Npad * KLD;           // [Npad][KLD]   dO
-    float* Ql = (float*)(Ds + (size_t)Npad * KLD);// [Npad] lse
+    float* Ql = (float*)(Ds + (size_t)Npad * KLD);// [Npad] lse * log2(e)
     float* Qd = Ql + Npad;                        // [Npad] delta
     int* Qi = (int*)(Qd + Npad);                  // [Npad] info
-    float* tab = (float*)(Qi + Npad);             // MODE 0: [T2]
+    float* tab = (float*)(Qi + Npad);             // MODE 0: [T2], log2 units
     const int part = blockIdx.x % ksplit, bwh = blockIdx.x / ksplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
@@ -589,18 +659,18 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
     float qmul = g.scale;
     if (MODE == 0) {
         const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
-        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h];
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
         C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
         qmul = __expf(fminf(logit_scale[h], LN100));
     }
-    stage_tile<HD>(g, qkv, rs, h * HD, b, w, 0, Npad, Qs, MODE == 0, qmul);
+    stage_tile<HD>(g, qkv, rs, h * HD, b, w, 0, Npad, Qs, MODE == 0, qmul * LOG2E);
     stage_tile<HD>(g, dout, C, h * HD, b, w, 0, Npad, Ds, false, 1.0f);
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
         const int inf = am_info(g, valid, b, w, i);
-        Qi[i] = MODE == 0 ? (((inf & 0xffff) + C0) | (inf & ~0xffff)) : inf;
+        Qi[i] = MODE == 0 ? ((((inf & 0xffff) + C0) << 2) | (inf & ~0xffff)) : inf;
         float L = 0.f, D = 0.f;
         if (i < g.N) {
-            L = lse[((int64_t)bw * g.H + h) * g.N + i];
+            L = lse[((int64_t)bw * g.H + h) * g.N + i] * LOG2E;
             D = delta[am_token(g, b, w, i) * g.H + h];
         }
         Ql[i] = L;
@@ -609,13 +679,15 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
     __syncthreads();
 
     const int ntile = (g.N + 15) / 16;
+    const int nfull64 = (g.N / 64) * 64;
     for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * (blockDim.x >> 6)) {
         const int nk = kt * 16 + fc;
         const bool kok = nk < g.N;
         const int nkc = kok ? nk : g.N - 1;
         const int64_t tk = am_token(g, b, w, nkc);
-        const int kinf = kok ? am_info(g, valid, b, w, nkc) : AM_PAD;
-        const int bk = kinf & 0xffff, regk = (kinf >> 16) & 0xff;
+        const int kinf = am_info(g, valid, b, w, nkc);          // clamped key: its column is simply not stored
+        const char* tabk = (const char*)tab - 4 * (kinf & 0xffff);
+        const int regk = (kinf >> 16) & 0xff, vk = kinf;
         bf16x8_t kf[HD / 32], vf[HD / 32];
         {
             float f[HD / 32][8];
@@ -638,46 +710,10 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
         f32x4_t dk[HD / 16], dv[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
-
-        for (int qb = 0; qb < Npad; qb += 32) {
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-#pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
-                const int o0 = (qb + fc) * KLD + ks * 32 + fg * 8, o1 = (qb + 16 + fc) * KLD + ks * 32 + fg * 8;
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o0), kf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o1), kf[ks], s1, 0, 0, 0);
-                p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o0), vf[ks], p0, 0, 0, 0);
-                p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o1), vf[ks], p1, 0, 0, 0);
-            }
-            const int4 i0 = *(const int4*)(Qi + qb + 4 * fg), i1 = *(const int4*)(Qi + qb + 16 + 4 * fg);
-            const float4 l0 = *(const float4*)(Ql + qb + 4 * fg), l1 = *(const float4*)(Ql + qb + 16 + 4 * fg);
-            const float4 d0 = *(const float4*)(Qd + qb + 4 * fg), d1 = *(const float4*)(Qd + qb + 16 + 4 * fg);
-            const int qi[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-            const float L[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-            const float D[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-            bf16x8_t pb, dsb;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float sv = s[r];
-                if (MODE == 0) {
-                    sv += tab[(qi[r] & 0xffff) - bk];
-                    sv = (((qi[r] >> 16) & 0xff) != regk) ? sv - 100.0f : sv;
-                } else {
-                    sv = (qi[r] & kinf & 1) ? sv : sv - 10000.0f;
-                }
-                const float p = ((qi[r] | kinf) & AM_PAD) ? 0.f : __expf(sv - L[r]);
-                pb[r] = (bf16)p;
-                dsb[r] = (bf16)(p * (dp[r] - D[r]));
-            }
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d) {
-                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ds, KLD, d * 16, qb, lane), pb, dv[d], 0, 0, 0);
-                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Qs, KLD, d * 16, qb, lane), dsb, dk[d], 0, 0, 0);
-            }
-        }
-        // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc
+        int qb = 0;
+        for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        for (; qb < Npad; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc; dk was accumulated against q~ * log2(e)
         if (kok) {
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) {
@@ -702,7 +738,7 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { kh[d][r] *= kinv; dot += dk[d][r] * kh[d][r]; }
+                for (int r = 0; r < 4; ++r) { kh[d][r] *= kinv; dk[d][r] *= LN2; dot += dk[d][r] * kh[d][r]; }
             dot = sum4g(dot);
             if (kok) {
 #pragma unroll
@@ -718,7 +754,7 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
             for (int d = 0; d < HD / 16; ++d) {
                 U4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)dk[d][r];
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(dk[d][r] * LN2);
                 *(uint2*)(dqkv + tk * rs + C + h * HD + d * 16 + 4 * fg) = o.u;
             }
         }
@@ -800,15 +836,15 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
     return 0;
 }
 
-// workspace: delta [tokens * H] fp32 (caller-owned).  dqkv is fully written.
+// workspaces (caller-owned): delta [tokens * H] fp32; qt [tokens, H*hd] bf16 (MODE 0: normalised, scaled queries).  dqkv is fully written.
 extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
-                                   float* dlogit_scale, float* ws_delta, int dtype, hipStream_t stream) {
+                                   float* dlogit_scale, float* ws_delta, void* ws_qt, int dtype, hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
-    MV_CHECK_ARG(mode == 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale), "attn_bwd_mfma: null pointer");
+    MV_CHECK_ARG(mode == 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
     AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale};
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
@@ -817,16 +853,23 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                        ws_delta, ntok, H, hd);
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);
-    {
-        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
-        AM_DISPATCH(attn_bwd_dq_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta,
-                    (bf16*)dqkv, dtable16, dlogit_scale, Npad, split);
-    }
-    {
-        const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 12 + (size_t)T2 * 4;
-        AM_DISPATCH(attn_bwd_dkv_mfma_k, bytes, g, (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta,
-                    (bf16*)dqkv, Npad, split);
-    }
+    const size_t bytes_q = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
+    const size_t bytes_k = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 12 + (size_t)T2 * 4;
+#define AM_BWD(HDV, MODEV, MASKV)                                                                                       \
+    do {                                                                                                                 \
+        if (am_set_lds(attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>, bytes_q, "attn_bwd_dq_mfma_k")) return 1;                  \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes_q, stream, g, \
+                           (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
+                           dlogit_scale, (bf16*)ws_qt, Npad, split);                                                                  \
+        if (am_set_lds(attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>, bytes_k, "attn_bwd_dkv_mfma_k")) return 1;                 \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes_k, stream, g, \
+                           (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
+                           Npad, split);                                                                                  \
+    } while (0)
+    if (mode == 0 && hd == 32) { if (shift > 0) AM_BWD(32, 0, true); else AM_BWD(32, 0, false); }
+    else if (mode == 0) { if (shift > 0) AM_BWD(64, 0, true); else AM_BWD(64, 0, false); }
+    else if (hd == 32) AM_BWD(32, 1, false);
+    else AM_BWD(64, 1, false);
     if (mode == 0) {
         MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
         const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
@@ -834,8 +877,8 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         int sp = 1;
         while ((int64_t)B * nW * H * sp < 1024 && sp * 2 * 8 <= items) sp *= 2;
         if (am_set_lds(attn_bwd_dbias_mfma_k<32>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv, table16,
-                           logit_scale, (const bf16*)dout, lse, ws_delta, dtable16, Npad, sp);
+        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv,
+                           (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, Npad, sp);
     }
     MV_LAUNCH_CHECK("attn_bwd_mfma");
     return 0;

@@ -253,9 +253,10 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
     dqkv = torch.empty_like(qkv)
     if _mfma_attn_ok(g, qkv.dtype):
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
+        qt = torch.empty((qkv.shape[0], g.H * g.hd), dtype=torch.bfloat16, device=qkv.device) if g.mode == 0 else None
         hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
         call("attn_bwd_mfma", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
-             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), dt(qkv))
+             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt), dt(qkv))
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
