@@ -117,6 +117,10 @@ int mvuld_add(const void* a, const void* b, void* y, int64_t n, int dtype, mvuld
  * RoBERTa hidden dropout; the same call with the same seed is the backward */
 int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, mvuld_stream_t stream);
 
+/* fp32 -> [hi | lo | hi] (mode 0) or [hi | hi | lo] (mode 1) bf16 rows of width 3*Kp: feeding both to mvuld_gemm_nt with K = 3*Kp
+ * gives a near-fp32 product (error ~2^-16) at matrix-core speed; used for the head's fp32 tail (Rs_GCN.py:57-70, GraphModel.py:201-209) */
+int mvuld_split_bf16x3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int Kp, int mode, mvuld_stream_t stream);
+
 /* PatchEmbed im2col (swin_transformer_v2.py:490) and PatchMerging's 2x2 gather-concat (:352-359) / its inverse */
 int mvuld_im2col_patch4(const float* img, void* cols, int B, int S, int dtype, mvuld_stream_t stream);
 int mvuld_patch_merge_gather(const void* src, void* dst, int B, int res, int C, int inverse, int dtype, mvuld_stream_t stream);

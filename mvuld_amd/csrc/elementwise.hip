@@ -463,3 +463,28 @@ extern "C" int mvuld_cpb_table_bwd(const float* coords, const float* W2, const f
     MV_LAUNCH_CHECK("cpb_table_bwd");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ fp32 -> 3 x bf16 split (near-fp32 GEMM on the bf16 matrix cores)
+// x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); a.b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi with fp32 accumulation (error ~2^-16).
+// dst row = [P0 | P1 | P2], each Kp wide (Kp >= K, zero padded):  mode 0 (A operand): hi, lo, hi ; mode 1 (B operand): hi, hi, lo.
+__global__ void split3_k(const float* __restrict__ src, int64_t ld, bf16* __restrict__ dst, int64_t rows, int K, int Kp, int mode) {
+    const int64_t total = rows * Kp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Kp;
+        const int k = (int)(i % Kp);
+        const float x = k < K ? src[r * ld + k] : 0.f;
+        const bf16 hi = (bf16)x;
+        const bf16 lo = (bf16)(x - (float)hi);
+        bf16* d = dst + r * 3 * Kp + k;
+        d[0] = hi;
+        d[Kp] = mode == 0 ? lo : hi;
+        d[2 * Kp] = mode == 0 ? hi : lo;
+    }
+}
+extern "C" int mvuld_split_bf16x3(const float* src, int64_t ld, void* dst, int64_t rows, int K, int Kp, int mode, hipStream_t stream) {
+    MV_CHECK_ARG(src && dst && rows > 0 && K > 0 && Kp >= K && Kp % 8 == 0 && (mode == 0 || mode == 1), "split_bf16x3: bad args");
+    const int grid = (int)min((int64_t)4096, cdiv(rows * Kp, 256));
+    hipLaunchKernelGGL(split3_k, dim3(grid), dim3(256), 0, stream, src, ld, (bf16*)dst, rows, K, Kp, mode);
+    MV_LAUNCH_CHECK("split_bf16x3");
+    return 0;
+}

@@ -10,6 +10,8 @@ Execution differences (results identical up to float rounding):
 ``g`` is a ``mvuld_amd.graph.BatchedGraph`` (the dgl stand-in); ``g.ndata['HGATOUTPUT'/'HFGATOUTPUT']`` are set
 as in the reference (:180-181).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F   # noqa: F401  (API parity; no torch compute is used on the path)
@@ -308,7 +310,8 @@ class Multi_DefectModel_new_GCN(nn.Module):
         self.config = config
         self.num_classes = config.MODEL.NUM_CLASSES
         self.act_dtype = act_dtype
-        self.tail_fp32 = True
+        self.tail_fp32 = True           # eps-free l2norm over nodes, final BatchNorm + classifier: fp32 storage
+        self.chain_fp32 = os.environ.get("MVULD_CHAIN_FP32", "1") == "1"   # the 8 Rs_GCN blocks
         hfeat, embfeat, numheads = 512, 768, 4
         self.p_gat, self.p_mlp, self.p_hidden = 0.2, 0.2, 0.2
         self.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
@@ -340,6 +343,9 @@ class Multi_DefectModel_new_GCN(nn.Module):
         ad = self.act_dtype
         tr = self.training
         hip.require_gpu(img_embedding, func_text_embedding)
+        # bf16 mode: the fp32 tail's GEMMs run as 3-term bf16 splits on the matrix cores (error ~2^-16); the fp32 parity
+        # mode keeps exact fp32 FMA GEMMs.  (Set here so that this step's backward sees the same choice.)
+        ops.USE_SPLIT3[0] = (ad == torch.bfloat16)
         B = g.batch_size
         img_embedding = ops.cast(img_embedding.contiguous(), ad) if img_embedding.dtype != ad else img_embedding
         func_text_embedding = ops.cast(func_text_embedding.contiguous(), ad) if func_text_embedding.dtype != ad else func_text_embedding
@@ -370,9 +376,11 @@ class Multi_DefectModel_new_GCN(nn.Module):
         # numerically the touchiest part of the model (a residual chain feeding a difference of near-equal terms):
         # they run with fp32 storage even when the encoders run in bf16.
         tail = torch.float32 if self.tail_fp32 else ad
-        v = cast_to(v, tail)
+        chain = torch.float32 if self.chain_fp32 else ad
+        v = cast_to(v, chain)
         for i in range(1, 9):
             v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
+        v = cast_to(v, tail)
         h_feature = _L2NormMeanFn.apply(v, B)                                     # l2norm over nodes + mean (:201-204)
         all_feats = _ConcatColsFn.apply(cast_to(x, tail), h_feature, cast_to(t, tail))
         return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,

@@ -16,6 +16,7 @@ from .hip import call, ptr, dt
 WEIGHT_EPOCH = [0]
 FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU kernel
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
+USE_SPLIT3 = [False]                 # fp32 GEMMs (the head's fp32 tail) as 3-term bf16 splits on the matrix cores
 USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
 
 
@@ -97,6 +98,21 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
         ldaux = aux.stride(-2)
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("gemm_nt: bias must be fp32")
+    if (a.dtype == torch.float32 and b.dtype == torch.float32 and USE_SPLIT3[0] and not FORCE_SIMPLE_GEMM[0] and M >= 64 and N >= 64
+            and (aux is None or aux.dtype == out.dtype)):
+        # near-fp32 product on the bf16 matrix cores: both operands split into hi/lo bf16 parts concatenated along K
+        Kp = (K + 7) // 8 * 8
+        ra, rb = M * batch, N * batch
+        if (batch == 1 or (sa == M * lda and sb == N * ldb)):
+            a3 = torch.empty((ra, 3 * Kp), dtype=torch.bfloat16, device=a.device)
+            b3 = torch.empty((rb, 3 * Kp), dtype=torch.bfloat16, device=a.device)
+            call("split_bf16x3", ptr(a), lda, ptr(a3), ra, K, Kp, 0)
+            call("split_bf16x3", ptr(b), ldb, ptr(b3), rb, K, Kp, 1)
+            if hip.TIMING.enabled:
+                hip.TIMING.annotate("gemm_nt_mfma_bf16(split3 fp32)", 6.0 * M * N * Kp * batch)
+            call("gemm_nt", ptr(a3), 3 * Kp, M * 3 * Kp, ptr(b3), 3 * Kp, N * 3 * Kp, ptr(out), ldc, sc, M, N, 3 * Kp, batch, ptr(bias), epi,
+                 ptr(aux), ldaux or 0, saux, float(alpha), out_mode, splitk, hip.BF16, dt(out), 0)
+            return out
     if hip.TIMING.enabled:
         mfma = (a.dtype == torch.bfloat16 and K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and sa % 8 == 0 and sb % 8 == 0
                 and M >= 32 and N >= 32 and not FORCE_SIMPLE_GEMM[0])
