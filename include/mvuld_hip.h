@@ -62,10 +62,12 @@ int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dt
 int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta,
                         const void* residual, const float* rowscale, int rows_per_sample, void* y, float* mean,
                         float* rstd, int64_t rows, int C, float eps, int dtype, mvuld_stream_t stream);
-/* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta atomic accumulate */
+/* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta accumulate (+=).  `ws` (optional, fp32,
+ * ws_bytes >= 512*C) lends room for per-block column partials summed by a second kernel; without it the column sums
+ * are device atomics (slower: ~1.5M contended atomics per launch at C=768). */
 int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const float* rowscale, int rows_per_sample, void* dx, float* dgamma, float* dbeta,
-                        int64_t rows, int C, int dtype, mvuld_stream_t stream);
+                        int64_t rows, int C, float* ws, int64_t ws_bytes, int dtype, mvuld_stream_t stream);
 
 /* BatchNorm1d over a strided view: element (o,c,i) at o*so + c*sc + i*si, statistics over (o,i).
  * GraphModel.py:153,158,186,187,208 (swinbn, bn_text, bn_gat, bn_bbox, final_fc_bn) and Rs_GCN.py:27-34 (W[1]). */

@@ -112,6 +112,226 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy,
     }
 }
 
+// ---- bf16 fast path: 16-byte accesses.  A row of C elements is C/8 chunks; G = min(64, pow2ceil(C/8)) lanes share a row
+// (CPL = ceil(C/8/G) <= 2 chunks per lane), 64/G rows per wave, statistics by xor-shuffles inside the lane group.
+// Every load is unconditional on a clamped address (a predicated load makes the compiler branch and drain vmcnt per load,
+// which serialises the x / pre / residual round trips); only the stores are predicated.
+__device__ __forceinline__ float group_sum(float v, int G) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_xor(v, o, 64);
+        v += (o < G) ? t : 0.f;
+    }
+    return v;
+}
+
+template <int CPL, bool HAS_PRE, bool HAS_RES>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restrict__ x, const bf16* __restrict__ pre, bf16* __restrict__ xsum,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const bf16* __restrict__ res, const float* __restrict__ rowscale,
+                                                           int rows_per_sample, bf16* __restrict__ y, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int64_t rows, int C, int G, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sub = lane & (G - 1), rg = lane / G, rpw = 64 / G;
+    const int nch = C >> 3;
+    float ga[CPL][8], be[CPL][8];
+    int chc[CPL];
+    bool chok[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = sub + G * i;
+        chok[i] = ch < nch;
+        chc[i] = chok[i] ? ch : nch - 1;
+        const float4 g0 = *(const float4*)(gamma + chc[i] * 8), g1 = *(const float4*)(gamma + chc[i] * 8 + 4);
+        const float4 b0 = *(const float4*)(beta + chc[i] * 8), b1 = *(const float4*)(beta + chc[i] * 8 + 4);
+        ga[i][0] = g0.x; ga[i][1] = g0.y; ga[i][2] = g0.z; ga[i][3] = g0.w; ga[i][4] = g1.x; ga[i][5] = g1.y; ga[i][6] = g1.z; ga[i][7] = g1.w;
+        be[i][0] = b0.x; be[i][1] = b0.y; be[i][2] = b0.z; be[i][3] = b0.w; be[i][4] = b1.x; be[i][5] = b1.y; be[i][6] = b1.z; be[i][7] = b1.w;
+    }
+    const int64_t rstep = (int64_t)gridDim.x * 4 * rpw;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + w) * rpw; r0 < rows; r0 += rstep) {
+        const int64_t r = r0 + rg;
+        const bool rok = r < rows;
+        const int64_t rc = rok ? r : rows - 1;
+        bf16x8 a[CPL], p[CPL], rr[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            a[i] = *(const bf16x8*)(x + rc * C + chc[i] * 8);
+            if (HAS_PRE) p[i] = *(const bf16x8*)(pre + rc * C + chc[i] * 8);
+            if (HAS_RES) rr[i] = *(const bf16x8*)(res + rc * C + chc[i] * 8);
+        }
+        float sc = 1.0f;
+        if (rowscale) sc = rowscale[rc / rows_per_sample];
+        float v[CPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)a[i].v[e];
+                if (HAS_PRE) { t += (float)p[i].v[e]; a[i].v[e] = (bf16)t; t = (float)a[i].v[e]; }
+                t = chok[i] ? t : 0.f;
+                v[i][e] = t;
+                s += t;
+            }
+            if (HAS_PRE && xsum && rok && chok[i]) *(bf16x8*)(xsum + r * C + chc[i] * 8) = a[i];
+        }
+        s = group_sum(s, G);
+        const float mu = s / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = chok[i] ? v[i][e] - mu : 0.f; q += d * d; }
+        q = group_sum(q, G);
+        const float rs = rsqrtf(q / C + eps);
+        if (rok && sub == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = ((v[i][e] - mu) * rs * ga[i][e] + be[i][e]) * sc;
+                if (HAS_RES) t += (float)rr[i].v[e];
+                o.v[e] = (bf16)t;
+            }
+            if (rok && chok[i]) *(bf16x8*)(y + r * C + chc[i] * 8) = o;
+        }
+    }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_k(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ rowscale, int rows_per_sample, bf16* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int G, float* __restrict__ ws) {
+    __shared__ float accg[1024], accb[1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sub = lane & (G - 1), rg = lane / G, rpw = 64 / G;
+    const int nch = C >> 3;
+    for (int i = threadIdx.x; i < C; i += 256) { accg[i] = 0.f; accb[i] = 0.f; }
+    float ga[CPL][8], pg[CPL][8], pb[CPL][8];
+    int chc[CPL];
+    bool chok[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = sub + G * i;
+        chok[i] = ch < nch;
+        chc[i] = chok[i] ? ch : nch - 1;
+        const float4 g0 = *(const float4*)(gamma + chc[i] * 8), g1 = *(const float4*)(gamma + chc[i] * 8 + 4);
+        ga[i][0] = g0.x; ga[i][1] = g0.y; ga[i][2] = g0.z; ga[i][3] = g0.w; ga[i][4] = g1.x; ga[i][5] = g1.y; ga[i][6] = g1.z; ga[i][7] = g1.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
+    }
+    const int64_t rstep = (int64_t)gridDim.x * 4 * rpw;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + w) * rpw; r0 < rows; r0 += rstep) {
+        const int64_t r = r0 + rg;
+        const bool rok = r < rows;
+        const int64_t rc = rok ? r : rows - 1;
+        bf16x8 a[CPL], b[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            a[i] = *(const bf16x8*)(dy + rc * C + chc[i] * 8);
+            b[i] = *(const bf16x8*)(x + rc * C + chc[i] * 8);
+        }
+        const float mu = mean[rc], rs = rstd[rc];
+        float sc = 1.0f;
+        if (rowscale) sc = rowscale[rc / rows_per_sample];
+        float g[CPL][8], xh[CPL][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const bool ok = rok && chok[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = ok ? (float)a[i].v[e] * sc : 0.f;
+                xh[i][e] = ok ? ((float)b[i].v[e] - mu) * rs : 0.f;
+                pg[i][e] += d * xh[i][e];
+                pb[i][e] += d;
+                g[i][e] = d * ga[i][e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
+        }
+        s1 = group_sum(s1, G) / C;
+        s2 = group_sum(s2, G) / C;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = (bf16)(rs * (g[i][e] - s1 - xh[i][e] * s2));
+            if (rok && chok[i]) *(bf16x8*)(dx + r * C + chc[i] * 8) = o;
+        }
+    }
+    // column partials: fold the row groups of a wave by shuffles, then the waves take turns adding into the LDS accumulators
+    // (LDS float atomics run at about one lane per clock per CU)
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float tg = __shfl_xor(pg[i][e], o, 64), tb = __shfl_xor(pb[i][e], o, 64);
+                pg[i][e] += (o >= G) ? tg : 0.f;
+                pb[i][e] += (o >= G) ? tb : 0.f;
+            }
+        }
+    for (int wv = 0; wv < 4; ++wv) {
+        __syncthreads();
+        if (w == wv && rg == 0) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i)
+                if (chok[i]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { accg[chc[i] * 8 + e] += pg[i][e]; accb[chc[i] * 8 + e] += pb[i][e]; }
+                }
+        }
+    }
+    __syncthreads();
+    if (ws) {                                       // per-block partials, summed by layernorm_bwd_reduce_k
+        float* o = ws + (size_t)blockIdx.x * 2 * C;
+        for (int i = threadIdx.x; i < C; i += 256) { o[i] = accg[i]; o[C + i] = accb[i]; }
+        return;
+    }
+    for (int i = threadIdx.x; i < C; i += 256) {
+        if (dgamma) atomicAdd(dgamma + i, accg[i]);
+        if (dbeta) atomicAdd(dbeta + i, accb[i]);
+    }
+}
+
+// dgamma[c] += sum_b ws[b][c], dbeta[c] += sum_b ws[b][C + c]: 64 columns x 16 row groups per block, blockIdx.y = row slab
+__global__ __launch_bounds__(1024) void layernorm_bwd_reduce_k(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int cc = min(c, 2 * C - 1);
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = b0 + g; b < b1; b += 128) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int bb = b + 16 * u;
+            const float v = ws[(size_t)min(bb, nblk - 1) * 2 * C + cc];
+            a[u] += bb < b1 ? v : 0.f;
+        }
+    }
+    red[g][threadIdx.x & 63] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (g == 0 && c < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        if (c < C) { if (dgamma) atomicAdd(dgamma + c, t); }
+        else if (dbeta) atomicAdd(dbeta + c - C, t);
+    }
+}
+
+static inline int ln_group(int C) {          // lanes per row
+    int g = 1;
+    while (g < 64 && g * 8 < C) g <<= 1;
+    return g;
+}
+
 // y = residual + rowscale[row / rows_per_sample] * (LN(x + pre) * gamma + beta); pre/xsum/residual/rowscale optional
 extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
                                    const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd,
@@ -119,6 +339,28 @@ extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, c
     MV_CHECK_ARG(rows > 0 && C > 0 && C <= 64 * LN_MAXPL, "layernorm_fwd: rows=%lld C=%d unsupported (C<=1024)", (long long)rows, C);
     MV_CHECK_ARG(x && y && gamma && beta, "layernorm_fwd: null pointer");
     MV_CHECK_ARG(!rowscale || rows_per_sample > 0, "layernorm_fwd: rows_per_sample");
+    if (dtype == MVULD_BF16 && C % 8 == 0 && rows > 0 &&
+        (((uintptr_t)x | (uintptr_t)y | (uintptr_t)pre | (uintptr_t)xsum | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+        const int G = ln_group(C), rpw = 64 / G;
+        const int gridv = (int)min((int64_t)4096, cdiv(rows, (int64_t)4 * rpw));
+#define LN_FWD_VEC(CPL, P, R)                                                                                                          \
+    hipLaunchKernelGGL((layernorm_fwd_vec_k<CPL, P, R>), dim3(gridv), dim3(256), 0, stream, (const bf16*)x, (const bf16*)pre, (bf16*)xsum, \
+                       gamma, beta, (const bf16*)residual, rowscale, rows_per_sample, (bf16*)y, mean, rstd, rows, C, G, eps)
+        const int sel = (C / 8 <= G ? 0 : 4) | (pre ? 2 : 0) | (residual ? 1 : 0);
+        switch (sel) {
+            case 0: LN_FWD_VEC(1, false, false); break;
+            case 1: LN_FWD_VEC(1, false, true); break;
+            case 2: LN_FWD_VEC(1, true, false); break;
+            case 3: LN_FWD_VEC(1, true, true); break;
+            case 4: LN_FWD_VEC(2, false, false); break;
+            case 5: LN_FWD_VEC(2, false, true); break;
+            case 6: LN_FWD_VEC(2, true, false); break;
+            default: LN_FWD_VEC(2, true, true); break;
+        }
+#undef LN_FWD_VEC
+        MV_LAUNCH_CHECK("layernorm_fwd_vec");
+        return 0;
+    }
     const int grid = (int)min((int64_t)2048, cdiv(rows, 4));
     if (dtype == MVULD_F32)
         hipLaunchKernelGGL(layernorm_fwd_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (const float*)pre, (float*)xsum, gamma, beta,
@@ -132,9 +374,30 @@ extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, c
 
 extern "C" int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                    const float* rstd, const float* rowscale, int rows_per_sample, void* dx,
-                                   float* dgamma, float* dbeta, int64_t rows, int C, int dtype, hipStream_t stream) {
+                                   float* dgamma, float* dbeta, int64_t rows, int C, float* ws, int64_t ws_bytes, int dtype,
+                                   hipStream_t stream) {
     MV_CHECK_ARG(rows > 0 && C > 0 && C <= 64 * LN_MAXPL, "layernorm_bwd: rows=%lld C=%d unsupported", (long long)rows, C);
     MV_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+    if (dtype == MVULD_BF16 && C % 8 == 0 && rows > 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0) {
+        const int G = ln_group(C), rpw = 64 / G;
+        static const int capv = getenv("MVULD_LN_BWD_GRID") ? atoi(getenv("MVULD_LN_BWD_GRID")) : 1024;
+        int gridv = (int)min((int64_t)capv, cdiv(rows, (int64_t)4 * rpw));
+        float* part = nullptr;
+        if (ws && ws_bytes >= (int64_t)8 * C * 64) {                 // two-pass column sums when the caller lends a workspace
+            gridv = (int)min((int64_t)gridv, ws_bytes / ((int64_t)8 * C));
+            part = ws;
+        }
+        if (C / 8 <= G)
+            hipLaunchKernelGGL(layernorm_bwd_vec_k<1>, dim3(gridv), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, rowscale,
+                               rows_per_sample, (bf16*)dx, dgamma, dbeta, rows, C, G, part);
+        else
+            hipLaunchKernelGGL(layernorm_bwd_vec_k<2>, dim3(gridv), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, rowscale,
+                               rows_per_sample, (bf16*)dx, dgamma, dbeta, rows, C, G, part);
+        if (part && (dgamma || dbeta))
+            hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3(cdiv(2 * C, 64), 8), dim3(1024), 0, stream, part, gridv, C, dgamma, dbeta);
+        MV_LAUNCH_CHECK("layernorm_bwd_vec");
+        return 0;
+    }
     const int grid = (int)min((int64_t)1024, cdiv(rows, 4));
     if (dtype == MVULD_F32)
         hipLaunchKernelGGL(layernorm_bwd_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)dy, (const float*)x,

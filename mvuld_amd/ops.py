@@ -168,6 +168,18 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
     gemm_nt(dyT, xT, out=gw.view(N, K), out_mode=hip.OUT_ATOMIC, splitk=wgrad_splitk(N, K, M))
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Persistent fp32 scratch per device; kernels that borrow it run on one stream, so reuse is ordered."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_per_sample=1, pre=None, want_sum=False):
     rows, C = x.shape
     y = torch.empty_like(x)
@@ -182,8 +194,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_p
 def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sample=1):
     rows, C = x.shape
     dx = torch.empty_like(x)
+    ws = _workspace(x.device, 8 * 1024 * 1024)
     call("layernorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(rowscale), rows_per_sample, ptr(dx),
-         ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)), rows, C, dt(x))
+         ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)), rows, C, ptr(ws), ws.numel() * 4, dt(x))
     return dx
 
 
