@@ -94,14 +94,17 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
 
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
- * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes). */
+ * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).
+ * ws_part (optional, mode 0): fp32 room for one (2ws-1)^2 partial bias-table gradient per workgroup of the bias pass
+ * (<= B*nW*H*2 of them), summed by a second kernel; without it every workgroup adds its table with device atomics. */
 int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         void* out, float* lse, int dtype, mvuld_stream_t stream);
 int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
-                        float* dlogit_scale, float* ws_delta, void* ws_qt, int dtype, mvuld_stream_t stream);
+                        float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes,
+                        int dtype, mvuld_stream_t stream);
 
 /* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,

@@ -467,11 +467,22 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
 // entry of every (lane, register) LOOP-INVARIANT: tiles are aligned to image rows of the window (a q tile = up to 16 tokens of
 // one row, a key block = one row padded to 32 slots), a wave owns one (dy, q-part) and sweeps yq with yk = yq - dy, so dS is
 // summed in 8 registers per lane and only the final sums touch LDS / global atomics (~14x fewer atomics at w = 28).
-template <int HD>
-__global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
-                                                              const float* __restrict__ table16, const bf16* __restrict__ dout,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              float* __restrict__ dtable16, int Npad, int split) {
+// DPP row shifts inside a 16-lane row, zero fill: shl n -> lane i reads lane i+n, shr n -> lane i reads lane i-n.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// Work item of a wave = (q part of <=16 x positions, group of G vertical offsets dy in [0, ws)).  Each dy is swept together
+// with its complement dy - ws: image row yq pairs with key row yq - dy (+ ws while yq < dy), so every (item, yq) is exactly
+// G row tiles (16 queries x 32 key slots) and the q-side operands of a row are fetched once for all G of them.  The table
+// entry of a register is loop invariant between the two switches of a dy, so dS accumulates in registers; a flush folds the
+// 4-register diagonals of a lane row with DPP shifts before the LDS atomics (3x fewer of them).
+template <int HD, int G>
+__global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
+                                                             const float* __restrict__ table16, const bf16* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             float* __restrict__ dtable16, float* __restrict__ part_out, int Npad, int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KLD = HD + 8;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD] normalised keys
@@ -484,7 +495,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const 
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int lane = threadIdx.x & 63, fc = lane & 15, fg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // item / dy / key-row arithmetic stays scalar
     const int ws = g.ws;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);
@@ -495,85 +507,161 @@ __global__ __launch_bounds__(1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const 
 
     const int nqp = (ws + 15) / 16;               // q parts per image row
     const int qw = (ws + nqp - 1) / nqp;          // tokens per q part (<= 16)
-    const int nitem = W2 * nqp;                   // (dy, q part)
+    const int ngrp = (ws + G - 1) / G;
+    const int nitem = ngrp * nqp;
     const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
-    // key slots of this lane: tile t, row 4*fg + r  ->  xk = 16 t + 4 fg + r
+    const bf16* qt_h = qt + h * HD + fg * 8;
+    const bf16* do_h = dout + h * HD + fg * 8;
+    const float* lse_h = lse + ((int64_t)bw * g.H + h) * g.N;
+    const float* dl_h = delta + h;
     for (int item = part + split * wave; item < nitem; item += split * (blockDim.x >> 6)) {
-        const int dy = item / nqp - (ws - 1), qp = item % nqp;
+        const int grp = item / nqp, qp = item % nqp;
         const int xq = qp * qw + fc;
         const bool qv = fc < qw && xq < ws;
-        const int y0 = max(0, dy), y1 = min(ws, ws + dy);       // yq range with 0 <= yq - dy < ws
-        float acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-        // Everything that depends only on (lane, register) is hoisted out of the row sweep: the table entry (hence the
-        // bias value) and the x-part of the shift-mask region test.  The y-part of the region test is wave-uniform.
         const int xqc = min(xq, ws - 1);
         const int rxq = g.shift > 0 ? am_rid(g, wx * ws + xqc) : 0;
-        // bias[r] also carries the x-part of the shift mask (-100) and, for slots beyond the row (padding), -inf.
-        // (A pair that differs in both the x and the y region gets -200 instead of the reference's -100: both underflow
-        //  exp() to exactly 0 in fp32 against scores bounded by tau + 16.)
-        float bias[8];
+        // per register: key slot x = 16 t + 4 fg + r' (r = 4 t + r'); bit r of xmask = other x region, of pmask = beyond the row
+        unsigned xmask = 0, pmask = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
-            const int xkc = min(xk, ws - 1);
-            bias[r] = tab[(dy + ws - 1) * W2 + (xqc - xkc + ws - 1)];
-            if (g.shift > 0 && am_rid(g, wx * ws + xkc) != rxq) bias[r] -= 100.0f * LOG2E;
-            if (xk >= ws) bias[r] = NEG_BIG;
+            if (g.shift > 0 && am_rid(g, wx * ws + min(xk, ws - 1)) != rxq) xmask |= 1u << r;
+            if (xk >= ws) pmask |= 1u << r;
+        }
+        // bias[r] carries the table entry, the x part of the shift mask (-100) and, for slots beyond the row, -inf.
+        // (A pair that differs in both the x and the y region gets -200 instead of the reference's -100: both underflow
+        //  exp() to exactly 0 in fp32 against scores bounded by tau + 16.)
+        auto load_bias = [&](float* bj, int dyv) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int xkc = min((r >> 2) * 16 + 4 * fg + (r & 3), ws - 1);
+                float v = tab[(dyv + ws - 1) * W2 + (xqc - xkc + ws - 1)];
+                v = ((xmask >> r) & 1) ? v - 100.0f * LOG2E : v;
+                bj[r] = ((pmask >> r) & 1) ? NEG_BIG : v;
+            }
+        };
+        // dtab[dy][xq - xk] += acc: lane fc, register r' of tile t lands in column fc - r' + cb(t); the four registers of a
+        // diagonal sit in lanes fc..fc+3 of the row, so shl-folds give columns m = fc (16 lanes) and shr-folds m = fc - 3 < 0.
+        auto flush = [&](float* aj, int dyv) {
+            float* drow = dtab + (dyv + ws - 1) * W2;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = (qv && !((pmask >> (4 * t + r)) & 1)) ? aj[4 * t + r] : 0.f;
+                const float sm = a[0] + dpp_row<0x101>(a[1]) + dpp_row<0x102>(a[2]) + dpp_row<0x103>(a[3]);
+                const float sn = a[3] + dpp_row<0x111>(a[2]) + dpp_row<0x112>(a[1]);
+                const int cb = qp * qw - 16 * t - 4 * fg + ws - 1;
+                const int cm = cb + fc, cn = cb + fc - 3;
+                if (cm >= 0 && cm < W2 && sm != 0.f) atomicAdd(drow + cm, sm);
+                if (fc < 3 && cn >= 0 && cn < W2 && sn != 0.f) atomicAdd(drow + cn, sn);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) aj[r] = 0.f;
+        };
+        float acc[G][8], bias[G][8];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int dyj = grp * G + j;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[j][r] = 0.f;
+            load_bias(bias[j], dyj == 0 ? 0 : min(dyj, ws - 1) - ws);
         }
         const int ka0 = min(fc, ws - 1), ka1 = min(16 + fc, ws - 1);      // A rows: key slot (t, fc) of image row yk
-        // q-side operands of one image row: q~*log2e (from the dQ pass), dO, lse*log2e, delta
+        const int kb0 = ka0 * KLD + fg * 8, kb1 = ka1 * KLD + fg * 8;
+        // q-side operands of one image row: q~*log2e (from the dQ pass), dO, lse*log2e, delta.  Loads are unconditional
+        // (clamped lanes read a valid neighbour; their columns are never flushed).
         struct QRow { U8 q, d; float L2, D; };
         auto fetch = [&](int yq, QRow& o) {
             const int nq = yq * ws + xqc;
             const int64_t tq = Ktok[nq];
-            o.q.u = *(const uint4*)(qt + tq * C + h * HD + fg * 8);
-            o.d.u = qv ? *(const uint4*)(dout + tq * C + h * HD + fg * 8) : make_uint4(0, 0, 0, 0);
-            o.L2 = lse[((int64_t)bw * g.H + h) * g.N + nq] * LOG2E;
-            o.D = qv ? delta[tq * g.H + h] : 0.f;
+            o.q.u = *(const uint4*)(qt_h + tq * C);
+            o.d.u = *(const uint4*)(do_h + tq * C);
+            o.L2 = lse_h[nq];
+            o.D = dl_h[tq * g.H];
         };
-        auto row = [&](int yq, const QRow& o) {
-            const int yk = yq - dy;
-            const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yq) != am_rid(g, wy * ws + yk);     // wave-uniform
-            const int k0 = (yk * ws + ka0) * KLD + fg * 8, k1 = (yk * ws + ka1) * KLD + fg * 8;
-            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k0), o.q.v, s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + k1), o.q.v, s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k0), o.d.v, p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + k1), o.d.v, p1, 0, 0, 0);
-            const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            const float dp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-            const float c2 = (ydiff ? -100.0f * LOG2E : 0.f) - o.L2;
+        QRow cur, nxt;
+        fetch(0, cur);
+        for (int yq = 0; yq < ws; ++yq) {
+            fetch(min(yq + 1, ws - 1), nxt);
+            // a dy switches from its complement (dy - ws) to itself when the sweep reaches image row dy
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = fmaf(__builtin_amdgcn_exp2f(s[r] + bias[r] + c2), dp[r] - o.D, acc[r]);
-        };
-        // two rows per trip, the next pair in flight while this pair is multiplied
-        QRow a, c, na, nc;
-        int yq = y0;
-        if (yq < y1) fetch(yq, na);
-        if (yq + 1 < y1) fetch(yq + 1, nc);
-        for (; yq + 1 < y1; yq += 2) {
-            a = na; c = nc;
-            if (yq + 2 < y1) fetch(yq + 2, na);
-            if (yq + 3 < y1) fetch(yq + 3, nc);
-            row(yq, a);
-            row(yq + 1, c);
-        }
-        if (yq < y1) row(yq, na);
-        if (qv) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
-                if (xk < ws) atomicAdd(dtab + (dy + ws - 1) * W2 + (xq - xk + ws - 1), acc[r]);
+            for (int j = 0; j < G; ++j) {
+                const int dyj = grp * G + j;                               // wave-uniform
+                if (yq == dyj && dyj > 0 && dyj < ws) { flush(acc[j], dyj - ws); load_bias(bias[j], dyj); }
             }
+            // G row tiles in one basic block (no branches: the scheduler overlaps one tile's LDS reads and MFMAs with the
+            // previous tile's exp/fma).  The score MFMA starts from the bias, the dP MFMA from -delta; groups past the
+            // window edge (dy >= ws) compute on a clamped row and are never flushed.
+            const float L2 = cur.L2 * LOG2E;
+            const f32x4_t nD = {-cur.D, -cur.D, -cur.D, -cur.D};
+            const int rq = g.shift > 0 ? am_rid(g, wy * ws + yq) : 0;
+            bf16x8_t fk0[2], fk1[2], fv0[2], fv1[2];
+            auto frags = [&](int j, int slot) {
+                const int dyc = min(grp * G + j, ws - 1);
+                const int yk = yq - dyc + (yq < dyc ? ws : 0);
+                const int ko = yk * ws * KLD;                               // scalar
+                fk0[slot] = *(const bf16x8_t*)(Ks + ko + kb0); fk1[slot] = *(const bf16x8_t*)(Ks + ko + kb1);
+                fv0[slot] = *(const bf16x8_t*)(Vs + ko + kb0); fv1[slot] = *(const bf16x8_t*)(Vs + ko + kb1);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (j + 1 < G) frags(j + 1, (j + 1) & 1);                  // next tile's LDS reads fly under this tile's math
+                const int dyc = min(grp * G + j, ws - 1);
+                const int yk = yq - dyc + (yq < dyc ? ws : 0);
+                const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yk) != rq;
+                const f32x4_t b0 = {bias[j][0], bias[j][1], bias[j][2], bias[j][3]};
+                const f32x4_t b1 = {bias[j][4], bias[j][5], bias[j][6], bias[j][7]};
+                const f32x4_t s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0[j & 1], cur.q.v, b0, 0, 0, 0);
+                const f32x4_t s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1[j & 1], cur.q.v, b1, 0, 0, 0);
+                const f32x4_t p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[j & 1], cur.d.v, nD, 0, 0, 0);
+                const f32x4_t p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[j & 1], cur.d.v, nD, 0, 0, 0);
+                const float c2 = (ydiff ? -100.0f * LOG2E : 0.f) - L2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[j][r] = fmaf(__builtin_amdgcn_exp2f(s0[r] + c2), p0[r], acc[j][r]);
+                    acc[j][4 + r] = fmaf(__builtin_amdgcn_exp2f(s1[r] + c2), p1[r], acc[j][4 + r]);
+                }
+            }
+            // first use of the prefetched row pinned behind the tiles (keeps its vmcnt wait out of the MFMA block)
+            asm volatile("" : "+v"(nxt.q.v), "+v"(nxt.d.v), "+v"(nxt.L2), "+v"(nxt.D));
+            cur = nxt;
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int dyj = grp * G + j;
+            if (dyj < ws) flush(acc[j], dyj);
         }
     }
     __syncthreads();
+    if (part_out) {                                   // per-workgroup partial table, summed by attn_dbias_reduce_k
+        float* o = part_out + (size_t)blockIdx.x * T2;
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) o[i] = dtab[i];
+        return;
+    }
     for (int i = threadIdx.x; i < T2; i += blockDim.x) {
         const float v = dtab[i];
         if (v != 0.f) atomicAdd(dtable16 + (int64_t)i * g.H + h, v);
     }
+}
+
+// dtable16[i][h] += sum over (bw, p) of part[((bw * H + h) * split + p)][i]; blockIdx = (entry block, head, bw slab)
+__global__ __launch_bounds__(256) void attn_dbias_reduce_k(const float* __restrict__ part, float* __restrict__ dtable16, int T2, int H, int BW,
+                                                           int split) {
+    const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+    const int per = (BW + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(BW, b0 + per);
+    if (i >= T2) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = (b1 - b0) * split;                  // partials of this slab: rows ((bw * H + h) * split + p), p fastest
+    auto at = [&](int kk) { const int bw = b0 + kk / split, p = kk % split; return part[((size_t)(bw * H + h) * split + p) * T2 + i]; };
+    for (int k = 0; k < n; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const float t = at(min(k + u, n - 1)); a[u] += (k + u < n) ? t : 0.f; }
+    }
+    const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (v != 0.f) atomicAdd(dtable16 + (int64_t)i * H + h, v);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -840,7 +928,8 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
 extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
-                                   float* dlogit_scale, float* ws_delta, void* ws_qt, int dtype, hipStream_t stream) {
+                                   float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int dtype,
+                                   hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
@@ -873,12 +962,17 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     if (mode == 0) {
         MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
         const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
-        const int items = (2 * ws - 1) * ((ws + 15) / 16);
+        constexpr int DG = 4;                                   // dy per work item: ws = 28 -> 7 groups x 2 q parts = 14 items / 8 waves
+        const int items = ((ws + DG - 1) / DG) * ((ws + 15) / 16);
         int sp = 1;
-        while ((int64_t)B * nW * H * sp < 1024 && sp * 2 * 8 <= items) sp *= 2;
-        if (am_set_lds(attn_bwd_dbias_mfma_k<32>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv,
-                           (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, Npad, sp);
+        while ((int64_t)B * nW * H * sp < 256 && sp * 2 <= items) sp *= 2;
+        float* part = (ws_part && ws_part_bytes >= (int64_t)B * nW * H * sp * T2 * 4) ? ws_part : nullptr;
+        if (am_set_lds(attn_bwd_dbias_mfma_k<32, DG>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
+        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, DG>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv,
+                           (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
+        if (part)
+            hipLaunchKernelGGL(attn_dbias_reduce_k, dim3(cdiv(T2, 256), H, max(1, min(16, B * nW * sp / 8))), dim3(256), 0, stream, part, dtable16, T2, H,
+                               B * nW, sp);
     }
     MV_LAUNCH_CHECK("attn_bwd_mfma");
     return 0;

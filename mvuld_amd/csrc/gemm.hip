@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void gemm_nt_simple(GemmArgs g) {
 // ------------------------------------------------------------------------------------ MFMA bf16
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
 typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
 
 #define GT_BM 128
 #define GT_BN 128
@@ -157,17 +158,24 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
     for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i;
         s_row[i] = c >> 3; s_ch[i] = c & 7;
-        a_ptr[i] = A + (int64_t)min(m0 + s_row[i], g.M - 1) * g.lda + s_ch[i] * 8;
-        b_ptr[i] = B + (int64_t)min(n0 + s_row[i], g.N - 1) * g.ldb + s_ch[i] * 8;
+        a_ptr[i] = A + (int64_t)min(m0 + s_row[i], g.M - 1) * g.lda;
+        b_ptr[i] = B + (int64_t)min(n0 + s_row[i], g.N - 1) * g.ldb;
     }
-    uint4 ra[4], rb[4];
+    u32x4_t ra[4], rb[4];
+    // Loads are unconditional on clamped addresses and zeroed by a select afterwards: a predicated load makes the
+    // compiler branch around it and drain vmcnt, which serialises the eight round trips of a k-step.
+    // The zeroing select sits in stage_write, behind an empty asm that pins the first use of the loaded registers after the
+    // MFMA block -- otherwise the scheduler hoists the select (and the vmcnt wait it needs) in front of the MFMAs.
+    int k_loaded = 0;
     auto stage_load = [&](int kt) {
         const int k0 = kt * GT_BK;
+        k_loaded = k0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool ok = (k0 + s_ch[i] * 8) < g.K;
-            ra[i] = ok ? *(const uint4*)(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
-            rb[i] = ok ? *(const uint4*)(b_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+            const int kk = k0 + s_ch[i] * 8;
+            const int kc = kk < g.K ? kk : 0;
+            ra[i] = *(const u32x4_t*)(a_ptr[i] + kc);
+            rb[i] = *(const u32x4_t*)(b_ptr[i] + kc);
         }
     };
     auto stage_write = [&](int buf) {
@@ -175,9 +183,12 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
         char* sb = sa + 16384;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            u32x4_t ta = ra[i], tb = rb[i];
+            asm volatile("" : "+v"(ta), "+v"(tb));
+            const bool ok = (k_loaded + s_ch[i] * 8) < g.K;
             const int off = swz_off(s_row[i], s_ch[i]);
-            *(uint4*)(sa + off) = ra[i];
-            *(uint4*)(sb + off) = rb[i];
+            *(u32x4_t*)(sa + off) = ok ? ta : (u32x4_t){0u, 0u, 0u, 0u};
+            *(u32x4_t*)(sb + off) = ok ? tb : (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
 
@@ -244,19 +255,26 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
     const bool vec_ok = (g.out_mode == OUT_STORE) && (g.N % 8 == 0) && (g.ldc % 8 == 0) && (g.epi < EPI_GELU || (g.ldaux % 8 == 0));
     float bias8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (g.bias) {                           // wave-uniform; the loads inside are unconditional on clamped columns
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = g.bias[min(col + e, g.N - 1)];
+            bias8[e] = (col + e < g.N) ? t : 0.f;
+        }
+    }
 #pragma unroll 2
     for (int p = 0; p < 8 / EPH; ++p) {
         const int lr = p * 8 + (lane >> 3);
         const int row = m0 + wr * 64 + half * EROWS + lr;
-        if (row >= g.M || col >= g.N) continue;
+        const bool valid = row < g.M && col < g.N;
         const float4 va = *(const float4*)(ep + lr * GT_EPI_LD + lc);
         const float4 vb = *(const float4*)(ep + lr * GT_EPI_LD + lc + 4);
         float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         if (vec_ok) {
             float ax[8];
             if (g.epi >= EPI_MUL_DGELU) {
-                const TO* ap = aux + (int64_t)row * g.ldaux + col;
+                const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
                 if constexpr (sizeof(TO) == 4) {
                     const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
                     ax[0] = a0.x; ax[1] = a0.y; ax[2] = a0.z; ax[3] = a0.w; ax[4] = a1.x; ax[5] = a1.y; ax[6] = a1.z; ax[7] = a1.w;
@@ -281,6 +299,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
                 }
                 v[e] = x;
             }
+            if (!valid) continue;
             TO* cp = C + (int64_t)row * g.ldc + col;
             if constexpr (sizeof(TO) == 4) {
                 *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
                     *(bf16x8*)(aux + (int64_t)row * g.ldaux + col) = q;
                 }
             }
-        } else {
+        } else if (valid) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (col + e < g.N) epilogue_store<TO>(g, C, aux, row, col + e, v[e]);
@@ -350,15 +369,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
     int s_row[4], s_ch[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; s_row[i] = c >> 4; s_ch[i] = c & 15; }
-    uint4 ra[4], rb[4];
+    u32x4_t ra[4], rb[4];
+    int m_loaded = 0;
+    // unconditional loads on clamped addresses; the zeroing select waits in stage_write behind an asm pin (see gemm_nt_mfma_bf16)
     auto stage_load = [&](int mt) {
         const int m0 = mt * TN_BM;
+        m_loaded = m0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + s_row[i];
             const int ca = n0 + s_ch[i] * 8, cb = k0 + s_ch[i] * 8;
-            ra[i] = (m < M && ca < N) ? *(const uint4*)(A + (int64_t)m * lda + ca) : make_uint4(0, 0, 0, 0);
-            rb[i] = (m < M && cb < K) ? *(const uint4*)(B + (int64_t)m * ldb + cb) : make_uint4(0, 0, 0, 0);
+            const int64_t mc = min(m0 + s_row[i], M - 1);
+            ra[i] = *(const u32x4_t*)(A + mc * lda + (ca < N ? ca : 0));
+            rb[i] = *(const u32x4_t*)(B + mc * ldb + (cb < K ? cb : 0));
         }
     };
     auto stage_write = [&](int buf) {
@@ -366,8 +388,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
         bf16* sb = (bf16*)(smem + buf * 2 * TN_TILE_BYTES + TN_TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(uint4*)(sa + s_row[i] * TN_LD + s_ch[i] * 8) = ra[i];
-            *(uint4*)(sb + s_row[i] * TN_LD + s_ch[i] * 8) = rb[i];
+            u32x4_t ta = ra[i], tb = rb[i];
+            asm volatile("" : "+v"(ta), "+v"(tb));
+            const bool mok = (m_loaded + s_row[i]) < M;
+            const bool oka = mok && (n0 + s_ch[i] * 8) < N, okb = mok && (k0 + s_ch[i] * 8) < K;
+            *(u32x4_t*)(sa + s_row[i] * TN_LD + s_ch[i] * 8) = oka ? ta : (u32x4_t){0u, 0u, 0u, 0u};
+            *(u32x4_t*)(sb + s_row[i] * TN_LD + s_ch[i] * 8) = okb ? tb : (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
     f32x4_t acc[4][4];

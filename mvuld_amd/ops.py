@@ -284,8 +284,12 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
         qt = torch.empty((qkv.shape[0], g.H * g.hd), dtype=torch.bfloat16, device=qkv.device) if g.mode == 0 else None
         hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
+        part = None
+        if g.mode == 0:
+            part = _workspace(qkv.device, max(g.B * g.nW * g.H, 512) * (2 * g.ws - 1) ** 2 * 4)     # one table per workgroup
         call("attn_bwd_mfma", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
-             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt), dt(qkv))
+             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt), ptr(part), part.numel() * 4 if part is not None else 0,
+             dt(qkv))
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
