@@ -53,6 +53,11 @@ int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx,
 /* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
 int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);
 
+/* njobs independent 2-D transposes in one launch: jobs = device array of {const void* src; void* dst; int64 R, C, tile0}
+ * (40 bytes each; tile0 = running sum of ceil(R/64)*ceil(C/64) over the preceding jobs; total_tiles = the full sum).
+ * Refreshes every transposed weight copy (the W^T operands of the dgrad GEMMs, autograd of Linear) after an optimizer step. */
+int mvuld_transpose_batched(const void* jobs, int njobs, int64_t total_tiles, int dtype, mvuld_stream_t stream);
+
 /* out[c] += sum_r x[r*ld + c]  -- bias gradients (autograd of the `+ bias` in every Linear) */
 int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dtype, mvuld_stream_t stream);
 

@@ -35,6 +35,45 @@ extern "C" int mvuld_transpose(const void* src, void* dst, int R, int C, int bat
     return 0;
 }
 
+// Many independent transposes in one launch (the transposed weight copies the dgrad GEMMs read, refreshed after every
+// optimizer step): jobs[j] = {src, dst, R, C, first tile}; one 64x64 tile per workgroup, job found by binary search.
+struct TransposeJob { const void* src; void* dst; int64_t R, C, tile0; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batched_k(const TransposeJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TransposeJob jb = jobs[lo];
+    const int R = (int)jb.R, C = (int)jb.C;
+    const int t = (int)(blockIdx.x - jb.tile0), tc = (C + 63) / 64;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const T* src = (const T*)jb.src;
+    T* dst = (T*)jb.dst;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = min(r0 + i, R - 1), c = min(c0 + tx, C - 1);
+        tile[i][tx] = ldf(src + (int64_t)r * C + c);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) stf(dst + (int64_t)c * R + r, tile[tx][i]);
+    }
+}
+
+extern "C" int mvuld_transpose_batched(const void* jobs, int njobs, int64_t total_tiles, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(jobs && njobs > 0 && total_tiles > 0 && total_tiles < 2147483647LL, "transpose_batched: bad args");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_batched_k<T>, dim3((unsigned)total_tiles), dim3(256), 0, stream, (const TransposeJob*)jobs, njobs));
+    MV_LAUNCH_CHECK("transpose_batched");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ column sum (bias grads)
 // out[c] += sum_r x[r*ld + c]   (atomic accumulate into fp32)
 template <typename T>

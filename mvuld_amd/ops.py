@@ -39,6 +39,31 @@ def bump_weight_epoch():
     WEIGHT_EPOCH[0] += 1
 
 
+def refresh_store_transposes(store):
+    """Refresh every registered transposed weight copy of a ParamStore in one launch per dtype (called right after the
+    epoch moves: optimizer step / load_state_dict).  store._tjobs[dtype] = {"list": [(param, key, src, dst, R, C)], ...}."""
+    for dtype, reg in getattr(store, "_tjobs", {}).items():
+        if not reg["list"]:
+            continue
+        if reg["table"] is None:
+            rows, t0 = [], 0
+            for _, _, src, dst, R, C in reg["list"]:
+                rows.append([src.data_ptr(), dst.data_ptr(), R, C, t0])
+                t0 += math.ceil(R / 64) * math.ceil(C / 64)
+            reg["table"] = torch.tensor(rows, dtype=torch.int64).to(reg["list"][0][2].device)
+            reg["tiles"] = t0
+        call("transpose_batched", ptr(reg["table"]), len(reg["list"]), reg["tiles"], hip.F32 if dtype == torch.float32 else hip.BF16)
+        for p, key, *_ in reg["list"]:
+            setattr(p, key + "_epoch", WEIGHT_EPOCH[0])
+
+
+def _register_transpose(p, key, src, dst):
+    jobs = p._mv_store.__dict__.setdefault("_tjobs", {})
+    reg = jobs.setdefault(src.dtype, {"list": [], "table": None, "tiles": 0})
+    reg["list"].append((p, key, src, dst, src.shape[0], src.shape[1]))
+    reg["table"] = None
+
+
 def weight(p: torch.Tensor, dtype) -> torch.Tensor:
     """Parameter as a GEMM operand of activation dtype `dtype` ([out, in], row-major)."""
     if dtype == torch.float32:
@@ -65,8 +90,11 @@ def weight_t(p: torch.Tensor, dtype) -> torch.Tensor:
         if c is None:
             c = torch.empty((w2.shape[1], w2.shape[0]), dtype=w.dtype, device=w.device)
         call("transpose", ptr(w2), ptr(c), w2.shape[0], w2.shape[1], 1, dt(w2))
+        fresh = getattr(p, key, None) is None
         setattr(p, key, c)
         setattr(p, key + "_epoch", WEIGHT_EPOCH[0])
+        if fresh and getattr(p, "_mv_store", None) is not None:
+            _register_transpose(p, key, w2, c)        # flat-store storage is stable: later refreshes are batched
     return c
 
 

@@ -74,6 +74,8 @@ class ParamStore:
         else:
             self.flat16.copy_(self.flat)
         ops.bump_weight_epoch()
+        if self.flat.is_cuda:
+            ops.refresh_store_transposes(self)
 
     def segment(self, prefix):
         """[(start, end)] flat ranges (one per group) covering the parameters whose name starts with `prefix`."""
@@ -124,7 +126,8 @@ class FusedAdamW(torch.optim.Optimizer):
                  st.exp_avg_sq.data_ptr() + 4 * a, st.flat16.data_ptr() + 2 * a, b - a, float(grp["lr"]), float(b1), float(b2),
                  float(grp["eps"]), float(grp["weight_decay"]), self._step, ptr(coef))
         self._clipped = False
-        ops.bump_weight_epoch()           # transposed weight copies are stale now
+        ops.bump_weight_epoch()           # transposed weight copies are stale now: refresh the registered ones together
+        ops.refresh_store_transposes(st)
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grad()
