@@ -5,6 +5,7 @@ arithmetic operation is a ``libmvuld_hip.so`` call.  Tensors are contiguous; act
 f32 or bf16, parameters / gradients / statistics fp32.
 """
 import math
+import os
 
 import torch
 
@@ -181,7 +182,12 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
     if (w_param is not None and dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dyT is None and not FORCE_SIMPLE_GEMM[0]
             and USE_TN_WGRAD[0]):
         tiles = math.ceil(N / 128) * math.ceil(K / 128)
-        splitk = max(1, min(math.ceil(M / 64 / 4), 1024 // tiles))
+        # Split the token contraction so that tiles x splitk fills whole rounds of the 512 workgroup slots (2 per CU): one
+        # round when it fills >= 90 % of them, else two; more splits only add fp32 atomics (measured: tools/bench_gemm.py).
+        sk1, sk2 = max(1, 512 // tiles), max(1, 1024 // tiles)
+        f1, f2 = tiles * sk1 / 512.0, tiles * sk2 / 1024.0
+        splitk = sk1 if (f1 >= 0.9 or f2 <= f1 + 0.05) else sk2
+        splitk = max(1, min(math.ceil(M / 64 / 4), splitk))
         hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
         call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(grad_of(w_param)), K, M, N, K,
              ptr(grad_of(b_param)) if b_param is not None else None, splitk)
