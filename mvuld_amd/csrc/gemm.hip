@@ -121,7 +121,7 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offs
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename TO, int NBUF>
+template <typename TO, int NBUF, bool GLDS = false>
 __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,6 +192,31 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
         }
     };
 
+    // GLDS (K % 64 == 0, double buffer): the tile goes global -> LDS by LDS-DMA, no VGPR staging and no ds_write.  One
+    // instruction fills 1 KiB = 8 tile rows in lane order, so lane l fetches the chunk that the XOR swizzle stores in slot l & 7.
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    const bf16* ga_ptr[4];
+    const bf16* gb_ptr[4];
+    if (GLDS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            ga_ptr[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + ch * 8;
+            gb_ptr[i] = B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + ch * 8;
+        }
+    }
+    auto stage_glds = [&](int kt, int buf) {
+        const int k0 = kt * GT_BK;
+        char* sa = smem + buf * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(ga_ptr[i] + k0), (lds_vp)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gb_ptr[i] + k0), (lds_vp)(sa + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+
     f32x4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -199,8 +224,13 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     if (kt0 < kt1) {
-        stage_load(kt0);
-        if (NBUF == 2) stage_write(0);
+        if (GLDS) {
+            stage_glds(kt0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            stage_load(kt0);
+            if (NBUF == 2) stage_write(0);
+        }
     }
     if (NBUF == 2) __syncthreads();
     int cur = 0;
@@ -211,7 +241,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
             stage_write(0);
             __syncthreads();
         }
-        if (more) stage_load(kt + 1);
+        if (more) { if (GLDS) stage_glds(kt + 1, cur ^ 1); else stage_load(kt + 1); }
         const char* sa = smem + cur * 32768;
         const char* sb = sa + 16384;
 #pragma unroll
@@ -229,7 +259,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (NBUF == 2) {
-            if (more) stage_write(cur ^ 1);
+            if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of tile kt+1 has landed
+            else if (more) stage_write(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
@@ -495,15 +526,26 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
     if (use_mfma) {
         const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(N, GT_BN);
         dim3 grid(tiles_m * tiles_n, batch * splitk);
-        static int variant = -1;             // MVULD_GEMM_NBUF=1|2 selects the LDS pipelining variant (default 1)
-        if (variant < 0) { const char* e = getenv("MVULD_GEMM_NBUF"); variant = (e && e[0] == '2') ? 2 : 1; }
+        // Variant: a long contraction (K >= 1024) on a grid that fits the chip at 2 workgroups / CU anyway runs the double-buffered
+        // LDS-DMA loop (one barrier per k-step; the near-fp32 head GEMMs: -6 %); everything else the single-buffer loop at
+        // 3 workgroups / CU, whose extra resident tile hides prologue / epilogue better than the deeper pipeline does (A/B in the
+        // full step: equal or better).  MVULD_GEMM_NBUF=1|2|3 forces single | double | double + LDS-DMA.
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("MVULD_GEMM_NBUF"); forced = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
+        const bool small_grid = (int64_t)tiles_m * tiles_n * batch * splitk <= 512;
+        const int variant = forced ? forced : (K >= 1024 && K % GT_BK == 0 && small_grid ? 3 : 1);
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
+            (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
+            (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
             attr = true;
         }
-        if (variant == 2) {
+        if (variant == 3 && K % GT_BK == 0) {
+            if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16<float, 2, true>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((gemm_nt_mfma_bf16<bf16, 2, true>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
+        } else if (variant >= 2) {
             if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16<float, 2>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
             else hipLaunchKernelGGL((gemm_nt_mfma_bf16<bf16, 2>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
         } else {
