@@ -278,20 +278,21 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-__global__ void attn_delta_k(const bf16* __restrict__ out, const bf16* __restrict__ dout, float* __restrict__ delta, int64_t ntok, int H, int hd) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // over tokens * H
-    if (i >= ntok * H) return;
-    const bf16* o = out + i * hd;
-    const bf16* d = dout + i * hd;
+// one lane per 16-byte chunk (consecutive lanes read consecutive memory), hd/8 lanes fold one (token, head)
+__global__ __launch_bounds__(256) void attn_delta_k(const bf16* __restrict__ out, const bf16* __restrict__ dout, float* __restrict__ delta,
+                                                    int64_t ntok, int H, int hd) {
+    const int cpr = hd >> 3;                                                  // chunks per (token, head): 4 or 8
+    const int64_t nchunk = ntok * H * cpr;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cc = c < nchunk ? c : nchunk - 1;
+    U8 a, d;
+    a.u = *(const uint4*)(out + cc * 8);
+    d.u = *(const uint4*)(dout + cc * 8);
     float s = 0.f;
-    for (int e = 0; e < hd; e += 8) {
-        U8 a, c;
-        a.u = *(const uint4*)(o + e);
-        c.u = *(const uint4*)(d + e);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += (float)a.e[k] * (float)c.e[k];
-    }
-    delta[i] = s;
+    for (int k = 0; k < 8; ++k) s += (float)a.e[k] * (float)d.e[k];
+    for (int o = 1; o < cpr; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (c < nchunk && (c % cpr) == 0) delta[c / cpr] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
@@ -938,7 +939,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
     const int64_t ntok = (int64_t)B * nW * N;
-    hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H, 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
+    hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H * (hd / 8), 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
                        ws_delta, ntok, H, hd);
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);

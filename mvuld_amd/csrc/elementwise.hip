@@ -91,12 +91,43 @@ __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t
     if (ty == 0 && c < N) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
+// bf16, 16-byte loads: 8 lanes cover 64 columns of a row (one 128-byte line), 32 rows per pass
+__global__ __launch_bounds__(256) void colsum_vec_k(const bf16* __restrict__ x, int64_t ld, float* __restrict__ out, int64_t M, int N,
+                                                    int64_t rows_per_block) {
+    __shared__ float red[32][65];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + tx * 8;
+    const int cc = min(c0, N - 8);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0 + ty; r < r1; r += 32) {
+        const bf16x8 v = *(const bf16x8*)(x + r * ld + cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) atomicAdd(out + c, t);
+    }
+}
+
 extern "C" int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dtype, hipStream_t stream) {
     MV_CHECK_ARG(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad args");
     int64_t nby = min((int64_t)512, cdiv(M, 64));
     const int64_t rpb = cdiv(M, nby);
     nby = cdiv(M, rpb);
     dim3 grid((unsigned)cdiv(N, 64), (unsigned)nby);
+    if (dtype == MVULD_BF16 && N % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+        hipLaunchKernelGGL(colsum_vec_k, grid, dim3(256), 0, stream, (const bf16*)x, ld, out, M, N, rpb);
+        MV_LAUNCH_CHECK("colsum_vec");
+        return 0;
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_k<T>, grid, dim3(256), 0, stream, (const T*)x, ld, out, M, N, rpb));
     MV_LAUNCH_CHECK("colsum");
     return 0;
