@@ -87,6 +87,33 @@ def test_gemm_mfma_matches_simple(gpu):
     assert rel(fast, slow) < 1e-5
 
 
+def test_gemm_large_ragged_epilogues(gpu):
+    """A grid of several hundred tiles with ragged M / N / K tails (more workgroups than the chip holds at once, XCD-swizzled
+    tile order), every fused epilogue and both output dtypes, against the product of the bf16-rounded operands in fp32."""
+    from mvuld_amd import ops, hip
+    M, N, K = 6401, 2056, 520
+    g = torch.Generator().manual_seed(7)
+    a = (torch.rand((M, K), generator=g) - 0.5).to(torch.bfloat16)
+    b = (torch.rand((N, K), generator=g) - 0.5).to(torch.bfloat16)
+    bias = torch.rand((N,), generator=g) - 0.5
+    pre = ((torch.rand((M, N), generator=g) - 0.5) * 4).to(torch.bfloat16)
+    A, B_, Bi, P = a.to(gpu), b.to(gpu), bias.to(gpu), pre.to(gpu)
+    ref = (A.float() @ B_.float().t()).cpu()
+    out = ops.gemm_nt(A, B_, bias=Bi)
+    assert rel(out, ref + bias) < 1e-2
+    out32 = ops.gemm_nt(A, B_, bias=Bi, out_dtype=torch.float32)
+    assert rel(out32, ref + bias) < 2e-5
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
+    out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=aux)
+    assert rel(aux, ref + bias) < 1e-2 and rel(out, F.gelu(ref + bias)) < 1e-2
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_ADD_AUX, aux=P)
+    assert rel(out, ref + pre.float()) < 1e-2
+    p = pre.float().clone().requires_grad_(True)
+    F.gelu(p).sum().backward()
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_DGELU, aux=P)
+    assert rel(out, ref * p.grad) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_colsum(gpu, dtype):
     from mvuld_amd import ops
