@@ -189,9 +189,23 @@ def make_roofline(fam, ms_per_step):
     else:
         ach = d["bytes"] / sec / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4)}
-    r.update({"traffic": None, "kernel": name, "launches_per_step": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["n"]), 2),
+    r.update({"traffic": measured_traffic(name), "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.csv)",
+              "kernel": name, "launches_per_step": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["n"]), 2),
               "kernel_ms_per_step": round(d["ms"], 3), "step_ms": round(ms_per_step, 3), "top_kernels_ms": top})
     return r
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profile.py).  None when the summary has no such row."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    for row in csv.DictReader(open(path)):
+        if row["kernel"].strip('"') == kernel.split("(")[0]:
+            return round((float(row["read_MB_per_launch(x2 corrected)"]) + float(row["write_MB_per_launch"])) * 1e6)
+    return None
 
 
 def cpu_baseline(config, args):
