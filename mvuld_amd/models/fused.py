@@ -3,6 +3,8 @@ head in ONE forward/backward (the reference runs the encoders offline and caches
 mvuld/data/data_list.py:179-211,265-317).  Composition of the reference module
 boundaries: ``img_embedding = swin.forward_features(images)``, ``func_text_embedding = unixcoder.get_xcode_vec(ids)[1]``,
 ``logits = head(g, img_embedding, func_text_embedding)``.  State-dict prefixes: ``swin.``, ``unixcoder.``, ``head.``."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,7 @@ class FusedMVulD(nn.Module):
         for p in self.swin.head.parameters():
             p.requires_grad_(False)
         self.head = Multi_DefectModel_new_GCN(config, act_dtype=act_dtype)
+        self._side = None
         for n, p in self.head.named_parameters():
             if n.startswith(self.head.unused_parameter_prefixes):
                 p.requires_grad_(False)
@@ -35,7 +38,33 @@ class FusedMVulD(nn.Module):
         return self.swin.no_weight_decay_keywords()
 
     def forward(self, g, images, source_ids):
-        img = self.swin.forward_features(images)                       # [B,1024]
-        _, txt = self.unixcoder.get_xcode_vec(source_ids)              # [B,768]
+        """The two encoders are independent until the head: the text encoder runs on a second HIP stream so its kernels fill
+        the tails of the image encoder's launches (and vice versa); autograd replays each branch's backward on the stream its
+        forward ran on.  The side stream is joined before the head and, in backward, when the text encoder's first op has
+        launched its last kernel (its parameter gradients are atomics into the flat store, invisible to autograd's own
+        stream bookkeeping).  MVULD_CONCURRENT=0, or the per-launch timing mode, keeps everything on one stream."""
+        from .. import hip, ops
+        concurrent = images.is_cuda and os.environ.get("MVULD_CONCURRENT", "1") != "0" and not hip.TIMING.enabled
+        if not concurrent:
+            ops.on_backward_done("unixcoder", None, key="fused-join")
+            img = self.swin.forward_features(images)                   # [B,1024]
+            _, txt = self.unixcoder.get_xcode_vec(source_ids)          # [B,768]
+        else:
+            main = torch.cuda.current_stream(images.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=images.device)
+            side = self._side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _, txt = self.unixcoder.get_xcode_vec(source_ids)
+            img = self.swin.forward_features(images)
+            main.wait_stream(side)
+            txt.record_stream(main)
+
+            def join():                                                # runs inside backward, on the side stream
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(images.device))
+                main.wait_event(ev)
+            ops.on_backward_done("unixcoder", join, key="fused-join")
         g.ndata["_FUNC_EMB"] = txt                                     # (per-node repeat is dead in the reference head)
         return self.head(g, img, txt)

@@ -26,13 +26,18 @@ USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpo
 _BACKWARD_DONE = {}
 
 
-def on_backward_done(tag, fn):
-    _BACKWARD_DONE[tag] = fn
+def on_backward_done(tag, fn, key="default"):
+    """Register `fn` to run when the backward of encoder `tag` ("swin" | "unixcoder") has launched its last kernel (one
+    callback per (tag, key); None removes it)."""
+    d = _BACKWARD_DONE.setdefault(tag, {})
+    if fn is None:
+        d.pop(key, None)
+    else:
+        d[key] = fn
 
 
 def fire_backward_done(tag):
-    fn = _BACKWARD_DONE.get(tag)
-    if fn is not None:
+    for fn in list(_BACKWARD_DONE.get(tag, {}).values()):
         fn()
 
 
@@ -206,8 +211,8 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """Persistent fp32 scratch per device; kernels that borrow it run on one stream, so reuse is ordered."""
-    key = (device.type, device.index)
+    """Persistent fp32 scratch per (device, stream): kernels that borrow it run in stream order, so reuse is ordered."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = _WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)

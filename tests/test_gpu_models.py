@@ -362,3 +362,36 @@ def test_fused_train_step_vs_oracle(gpu, dtype):
         den = sum(float((sdr[k].detach() - old[k]).pow(2).sum()) for k in train_keys)
         print(f"[fused fp32] relative L2 error of the AdamW update: {(num / den) ** 0.5:.3e}")
         assert (num / den) ** 0.5 < 5e-2
+
+
+def test_fused_two_stream_matches_single_stream(gpu, monkeypatch):
+    """The text encoder runs on a side stream next to the image encoder (forward and backward); logits and every gradient
+    must equal the single-stream run up to the order of the fp32 atomic accumulations."""
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    from mvuld_amd.data import synthetic
+    config = _tiny_config(torch.bfloat16)
+    model = build_fused_model(config)
+    load_synth_into(model)
+    model = model.to(gpu).eval()               # eval: no dropout / DropPath draws, BN uses running stats -> deterministic inputs
+    f = config.FUSED
+    g, images, ids, labels = synthetic.make_batch([21, 22, 23, 24], config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g, images, ids, labels = g.to(gpu), images.to(gpu), ids.to(gpu), labels.to(gpu)
+    opt = build_optimizer(config, model)
+    store = model._mv_store
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("MVULD_CONCURRENT", mode)
+        store.zero_grad()
+        logits = model(g, images, ids)
+        loss, _ = cross_entropy(logits, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.setdefault(mode, []).append((logits.float().cpu(), store.grad.clone().cpu()))
+    (l0, g0), = res["0"]
+    for l1, g1 in res["1"]:
+        assert torch.allclose(l0, l1, atol=1e-6), "logits differ between the one- and two-stream forward"
+        assert float((g0 - g1).norm() / g0.norm()) < 1e-4
+        assert int((g1 != 0).sum()) == int((g0 != 0).sum())
+
