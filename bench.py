@@ -131,6 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # host enqueue time per step (the GPU runs behind it)
     fence()
     dt = time.perf_counter() - t0
     if world_size() > 1:
@@ -167,7 +168,7 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": round(fl * args.batch / 1e12, 2),
                        "achieved_tflops_per_gpu": round(fl * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
                        "frac_of_dense_bf16_peak": round(fl * args.batch / (ms_per_step * 1e-3) / PEAK_BF16, 4),
-                       "final_loss": round(loss_val, 5)},
+                       "host_enqueue_ms_per_step": round(host_ms, 2), "final_loss": round(loss_val, 5)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -74,6 +74,13 @@ union U4 { uint2 u; bf16x4_t v; bf16 e[4]; };
 // Stage `rows` token rows (HD wide, from column `coloff` of a [tokens, rowstride] matrix) starting at n0 into the
 // row-major LDS image rm[rows][HD+8], with optional L2 normalisation and scale.  Rows >= N are zero.  Four 16-byte loads
 // are kept in flight per thread.
+// XCD-aware order: workgroups b, b+8, ... share an XCD and its L2.  Giving each XCD a contiguous run of (window, head, part)
+// items keeps the heads of one window -- which read interleaved 64/128-byte column slices of the same qkv rows -- on one L2.
+__device__ __forceinline__ int am_xcd_order(int bid, int total) {
+    const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 template <int HD>
 __device__ __forceinline__ void stage_tile(const AttnGeom& g, const bf16* __restrict__ base, int64_t rowstride, int coloff, int b,
                                            int w, int n0, int rows, bf16* rm, bool normalize, float mul) {
@@ -205,7 +212,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
     float* tab = (float*)(Kinfo + Npad);          // MODE 0: [(2ws-1)^2], in log2 units
-    const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
+    const int bid = am_xcd_order(blockIdx.x, gridDim.x);
+    const int part = bid % qsplit, bwh = bid / qsplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
@@ -348,7 +356,8 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(Attn
     float* red = (float*)(Kinfo + Npad);          // [16]
     float* tab = red + 16;                        // MODE 0: [T2], log2 units
     const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
-    const int part = blockIdx.x % qsplit, bwh = blockIdx.x / qsplit;
+    const int bid = am_xcd_order(blockIdx.x, gridDim.x);
+    const int part = bid % qsplit, bwh = bid / qsplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
@@ -492,7 +501,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const b
     float* tab = (float*)(Ktok + Npad);           // [T2]  log2 units
     const int W2 = 2 * g.ws - 1, T2 = W2 * W2;
     float* dtab = tab + T2;                       // [T2]
-    const int part = blockIdx.x % split, bwh = blockIdx.x / split;
+    const int bid = am_xcd_order(blockIdx.x, gridDim.x);
+    const int part = bid % split, bwh = bid / split;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const b
     }
     __syncthreads();
     if (part_out) {                                   // per-workgroup partial table, summed by attn_dbias_reduce_k
-        float* o = part_out + (size_t)blockIdx.x * T2;
+        float* o = part_out + (size_t)bid * T2;
         for (int i = threadIdx.x; i < T2; i += blockDim.x) o[i] = dtab[i];
         return;
     }
@@ -739,7 +749,8 @@ __global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(Att
     float* Qd = Ql + Npad;                        // [Npad] delta
     int* Qi = (int*)(Qd + Npad);                  // [Npad] info
     float* tab = (float*)(Qi + Npad);             // MODE 0: [T2], log2 units
-    const int part = blockIdx.x % ksplit, bwh = blockIdx.x / ksplit;
+    const int bid = am_xcd_order(blockIdx.x, gridDim.x);
+    const int part = bid % ksplit, bwh = bid / ksplit;
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
