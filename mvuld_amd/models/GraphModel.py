@@ -340,22 +340,21 @@ class Multi_DefectModel_new_GCN(nn.Module):
         self.unused_parameter_prefixes = ("fconly.", "ln_text.", "hbn.", "hln.", "hfc.")
 
     def forward(self, g, img_embedding, func_text_embedding):
+        """Reference signature (GraphModel.py:151-211).  The graph branch depends on neither encoder output, so the fused model
+        may run it early on another stream: forward == forward_join(img, text, forward_graph(g))."""
+        return self.forward_join(g, img_embedding, func_text_embedding, self.forward_graph(g))
+
+    def forward_graph(self, g):
+        """Graph branch (:163-204): GAT x2 -> MLP -> unbatch/pad -> Rs_GCN x8 -> l2norm over nodes + mean  => [B, 512]."""
         ad = self.act_dtype
         tr = self.training
-        hip.require_gpu(img_embedding, func_text_embedding)
         # bf16 mode: the fp32 tail's GEMMs run as 3-term bf16 splits on the matrix cores (error ~2^-16); the fp32 parity
         # mode keeps exact fp32 FMA GEMMs.  (Set here so that this step's backward sees the same choice.)
         ops.USE_SPLIT3[0] = (ad == torch.bfloat16)
         B = g.batch_size
-        img_embedding = ops.cast(img_embedding.contiguous(), ad) if img_embedding.dtype != ad else img_embedding
-        func_text_embedding = ops.cast(func_text_embedding.contiguous(), ad) if func_text_embedding.dtype != ad else func_text_embedding
-        # 1. image branch  (:153-154)
-        x = linear_act(batch_norm(img_embedding, self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
-        # 2. text branch   (:158-159)
-        t = linear_act(batch_norm(func_text_embedding, self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
-        # 3. graph branch  (:163-177)
         h = g.ndata["_UNIX_NODE_EMB"]
         bboxes = g.ndata["pos_emb"]
+        hip.require_gpu(h, bboxes)
         h = ops.cast(h.contiguous(), ad) if h.dtype != ad else h
         bboxes = ops.cast(bboxes.contiguous(), ad) if bboxes.dtype != ad else bboxes
         h = self.gat(g, h).view(h.shape[0], -1)
@@ -381,7 +380,18 @@ class Multi_DefectModel_new_GCN(nn.Module):
         for i in range(1, 9):
             v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
         v = cast_to(v, tail)
-        h_feature = _L2NormMeanFn.apply(v, B)                                     # l2norm over nodes + mean (:201-204)
+        return _L2NormMeanFn.apply(v, B)                                          # l2norm over nodes + mean (:201-204)
+
+    def forward_join(self, g, img_embedding, func_text_embedding, h_feature):
+        """Image branch (:153-154), text branch (:158-159), concat + final BatchNorm + classifier (:206-210)."""
+        ad = self.act_dtype
+        hip.require_gpu(img_embedding, func_text_embedding)
+        ops.USE_SPLIT3[0] = (ad == torch.bfloat16)
+        img_embedding = ops.cast(img_embedding.contiguous(), ad) if img_embedding.dtype != ad else img_embedding
+        func_text_embedding = ops.cast(func_text_embedding.contiguous(), ad) if func_text_embedding.dtype != ad else func_text_embedding
+        x = linear_act(batch_norm(img_embedding, self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        t = linear_act(batch_norm(func_text_embedding, self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        tail = torch.float32 if self.tail_fp32 else ad
         all_feats = _ConcatColsFn.apply(cast_to(x, tail), h_feature, cast_to(t, tail))
         return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
                           None, torch.float32)

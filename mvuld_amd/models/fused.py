@@ -49,17 +49,26 @@ class FusedMVulD(nn.Module):
             ops.on_backward_done("unixcoder", None, key="fused-join")
             img = self.swin.forward_features(images)                   # [B,1024]
             _, txt = self.unixcoder.get_xcode_vec(source_ids)          # [B,768]
+            hfeat = self.head.forward_graph(g)
         else:
             main = torch.cuda.current_stream(images.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=images.device)
             side = self._side
             side.wait_stream(main)
+            # Side stream: the text encoder and the head's graph branch (which needs neither encoder: many small launches
+            # that leave most of the chip idle), both under the image encoder's dense kernels on the main stream.  Host
+            # order text -> image -> graph: autograd replays later-created nodes first, so in backward the graph branch is
+            # enqueued at once, the image encoder next and the text encoder last -- whose first op, the last side-stream
+            # work of the step, fires the join below.
             with torch.cuda.stream(side):
                 _, txt = self.unixcoder.get_xcode_vec(source_ids)
             img = self.swin.forward_features(images)
+            with torch.cuda.stream(side):
+                hfeat = self.head.forward_graph(g)
             main.wait_stream(side)
             txt.record_stream(main)
+            hfeat.record_stream(main)
 
             def join():                                                # runs inside backward, on the side stream
                 ev = torch.cuda.Event()
@@ -67,4 +76,4 @@ class FusedMVulD(nn.Module):
                 main.wait_event(ev)
             ops.on_backward_done("unixcoder", join, key="fused-join")
         g.ndata["_FUNC_EMB"] = txt                                     # (per-node repeat is dead in the reference head)
-        return self.head(g, img, txt)
+        return self.head.forward_join(g, img, txt, hfeat)
