@@ -44,6 +44,10 @@ int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, in
                   float alpha, int out_mode, int splitk, int dtype_in, int dtype_out, int force_simple,
                   mvuld_stream_t stream);
 
+/* Opt-in for the experimental 256 x 256-tile, 4-stage LDS-DMA ring variant of mvuld_gemm_nt: products with K >= min_k
+ * (K % 32 == 0, >= 128 tiles, plain store) take it; 0 (default) = never.  No stream argument: host-side setting. */
+int mvuld_set_gemm_256_min_k(int min_k);
+
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
  * layout, fp32 atomic accumulate, contraction split over `splitk` workgroups); dbias[N] += column sums of dY when non-null.
  * The autograd of every nn.Linear weight/bias on the path (same call sites as mvuld_gemm_nt). */

@@ -87,11 +87,22 @@ def test_gemm_mfma_matches_simple(gpu):
     assert rel(fast, slow) < 1e-5
 
 
-def test_gemm_large_ragged_epilogues(gpu):
+@pytest.mark.parametrize("K,ring", [(520, False), (544, False), (544, True)])
+def test_gemm_large_ragged_epilogues(gpu, K, ring):
     """A grid of several hundred tiles with ragged M / N / K tails (more workgroups than the chip holds at once, XCD-swizzled
-    tile order), every fused epilogue and both output dtypes, against the product of the bf16-rounded operands in fp32."""
+    tile order), every fused epilogue and both output dtypes, against the product of the bf16-rounded operands in fp32.
+    ring=True routes the same products through the opt-in 256 x 256-tile LDS-DMA ring kernel (needs K % 32 == 0)."""
     from mvuld_amd import ops, hip
-    M, N, K = 6401, 2056, 520
+    hip.LIB.fn("mvuld_set_gemm_256_min_k")(32 if ring else 0)
+    try:
+        _gemm_large_ragged(gpu, K)
+    finally:
+        hip.LIB.fn("mvuld_set_gemm_256_min_k")(0)
+
+
+def _gemm_large_ragged(gpu, K):
+    from mvuld_amd import ops, hip
+    M, N = 6401, 2056                         # K = 544 (a multiple of 32) is eligible for the 256 x 256 LDS-DMA ring kernel
     g = torch.Generator().manual_seed(7)
     a = (torch.rand((M, K), generator=g) - 0.5).to(torch.bfloat16)
     b = (torch.rand((N, K), generator=g) - 0.5).to(torch.bfloat16)
