@@ -23,12 +23,20 @@ def short(n):
     return n[:60]
 
 
-rows = list(csv.DictReader(open(f"{src}/kt/r01_kernel_stats.csv")))
-with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
-    for r in rows[:40]:
-        w.writerow([r["Name"][:110], r["Calls"], f"{int(r['TotalDurationNs'])/1e6:.3f}", f"{float(r['AverageNs'])/1e3:.2f}", r["Percentage"]])
+def kernel_stats(sub, out):
+    rows = list(csv.DictReader(open(f"{src}/{sub}/r01_kernel_stats.csv")))
+    with open(out, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
+        for r in rows[:40]:
+            w.writerow([r["Name"][:110], r["Calls"], f"{int(r['TotalDurationNs'])/1e6:.3f}", f"{float(r['AverageNs'])/1e3:.2f}", r["Percentage"]])
+
+
+# kt: MVULD_CONCURRENT=0 (one stream: per-kernel durations comparable with bench.py's live HIP-event timing)
+# kt2: default two-stream run (durations of overlapping kernels stretch; the wall clock is what bench.py reports)
+kernel_stats("kt", f"profiles/{tag}_kernel_stats.csv")
+if os.path.exists(f"{src}/kt2/r01_kernel_stats.csv"):
+    kernel_stats("kt2", f"profiles/{tag}_kernel_stats_two_streams.csv")
 
 agg = collections.defaultdict(lambda: {"n": 0, "fetch": 0.0, "write": 0.0, "ns": 0})
 for kind in ("fetch", "write"):
