@@ -119,7 +119,9 @@ int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, 
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,
                         float* table16, int T2, int H, mvuld_stream_t stream);
 int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16,
-                        const float* dtable16, float* dW1, float* db1, float* dW2, int T2, int H, mvuld_stream_t stream);
+                        const float* dtable16, float* dW1, float* db1, float* dW2, int T2, int H,
+                        float* ws, int64_t ws_bytes, mvuld_stream_t stream);     /* ws (optional): >= ceil(T2/16)*(32*512+1536)*4 bytes of
+                        fp32 scratch for per-block partial sums (else ~1 M device atomics per call) */
 
 /* activation backward: mode 0 GELU(erf) with ref = pre-activation (Mlp, swin_transformer_v2.py:28; RoBERTa
  * intermediate); mode 1 ELU with ref = output (F.elu, GraphModel.py:154-187) */

@@ -261,9 +261,29 @@ __global__ void patch_merge_k(const T* __restrict__ src, T* __restrict__ dst, in
         else dst[i] = src[xi];
     }
 }
+// bf16, C % 8 == 0: one 16-byte chunk per thread (index arithmetic once per 8 channels)
+__global__ __launch_bounds__(256) void patch_merge_vec_k(const bf16* __restrict__ src, bf16* __restrict__ dst, int B, int res, int C8, int inverse) {
+    const int h = res / 2;
+    const int64_t total = (int64_t)B * h * h * 4 * C8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const int q = (int)((i / C8) % 4);
+        const int64_t t = i / (4 * (int64_t)C8);
+        const int j = (int)(t % h), ii = (int)((t / h) % h), b = (int)(t / ((int64_t)h * h));
+        const int64_t xi = (((int64_t)b * res + 2 * ii + (q & 1)) * res + 2 * j + (q >> 1)) * C8 + c;
+        if (inverse) ((bf16x8*)dst)[xi] = ((const bf16x8*)src)[i];
+        else ((bf16x8*)dst)[i] = ((const bf16x8*)src)[xi];
+    }
+}
 extern "C" int mvuld_patch_merge_gather(const void* src, void* dst, int B, int res, int C, int inverse, int dtype, hipStream_t stream) {
     MV_CHECK_ARG(src && dst && B > 0 && res > 0 && res % 2 == 0 && C > 0, "patch_merge_gather: bad args");
     const int64_t total = (int64_t)B * res * res * C;
+    if (dtype == MVULD_BF16 && C % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const int gridv = (int)min((int64_t)16384, cdiv(total / 8, 256));
+        hipLaunchKernelGGL(patch_merge_vec_k, dim3(gridv), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, B, res, C / 8, inverse);
+        MV_LAUNCH_CHECK("patch_merge_gather_vec");
+        return 0;
+    }
     const int grid = (int)min((int64_t)8192, cdiv(total, 256));
     DISPATCH_T(dtype, hipLaunchKernelGGL(patch_merge_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)src, (T*)dst, B, res, C, inverse));
     MV_LAUNCH_CHECK("patch_merge_gather");
@@ -355,15 +375,14 @@ __global__ __launch_bounds__(256) void mean_pool_fwd_k(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void mean_pool_bwd_k(const T* __restrict__ dout, const int* __restrict__ valid, T* __restrict__ dx,
                                                        int L, int C) {
-    __shared__ float cnt;
+    __shared__ float red[4];
     const int b = blockIdx.z, l = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (threadIdx.x == 0) {
-        float n = 0.f;
-        if (valid) for (int i = 0; i < L; ++i) n += valid[b * L + i];
-        else n = (float)L;
-        cnt = n;
-    }
+    float n = 0.f;                                  // number of valid tokens of this row: block-wide sum
+    if (valid) for (int i = threadIdx.x; i < L; i += 256) n += valid[b * L + i];
+    n = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
     __syncthreads();
+    const float cnt = valid ? red[0] + red[1] + red[2] + red[3] : (float)L;
     if (c >= C) return;
     const float m = valid ? (float)valid[b * L + l] : 1.0f;
     stf(dx + ((int64_t)b * L + l) * C + c, ldf(dout + (int64_t)b * C + c) * m / cnt);
@@ -457,7 +476,6 @@ __global__ __launch_bounds__(256) void cpb_fwd_k(const float* __restrict__ coord
                                                  const float* __restrict__ W2, float* __restrict__ hidden, float* __restrict__ table16,
                                                  int T2, int H) {
     __shared__ float hid[512];
-    __shared__ float red[16];
     const int i = blockIdx.x;
     const float cy = coords[2 * i], cx = coords[2 * i + 1];
     for (int j = threadIdx.x; j < 512; j += 256) {
@@ -466,26 +484,35 @@ __global__ __launch_bounds__(256) void cpb_fwd_k(const float* __restrict__ coord
         hidden[(int64_t)i * 512 + j] = v;
     }
     __syncthreads();
-    for (int h = 0; h < H; ++h) {
-        float s = hid[threadIdx.x] * W2[h * 512 + threadIdx.x] + hid[threadIdx.x + 256] * W2[h * 512 + threadIdx.x + 256];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) table16[(int64_t)i * H + h] = 16.0f / (1.0f + __expf(-s));
+    // one wave per head (4 in flight): 512 products as 8 per lane + a wave reduction, no block barriers
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int h = wv; h < H; h += 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = fmaf(hid[lane + 64 * k], W2[h * 512 + lane + 64 * k], s);
+        s = wave_sum(s);
+        if (lane == 0) table16[(int64_t)i * H + h] = 16.0f / (1.0f + __expf(-s));
     }
 }
 // dz[i,h] = dtable16 * t16*(1 - t16/16);  dW2[h,j] += dz*hid[i,j];  dhid[j] = sum_h dz*W2[h,j] (relu gate);
 // dW1[j,:] += dhid*coords[i];  db1[j] += dhid.   One block per chunk of CPB_ROWS table rows; thread <-> hidden
 // units j and j+256; per-block partials leave through fp32 atomics.
-#define CPB_ROWS 32
+#define CPB_ROWS 16
 #define CPB_MAXH 32
+// One block per chunk of CPB_ROWS table rows; thread <-> hidden units j and j+256.  The per-block sums leave either as one row of
+// `part` ([blocks][HH*512 + 1536]: dW2 | dW1 | db1, summed by cpb_bwd_reduce_k) or, without a workspace, through fp32 atomics
+// (~1 M contended atomics per launch: 4x slower).
+template <int HH>
 __global__ __launch_bounds__(256) void cpb_bwd_k(const float* __restrict__ coords, const float* __restrict__ W2, const float* __restrict__ hidden,
                                                  const float* __restrict__ table16, const float* __restrict__ dtable16,
-                                                 float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, int T2, int H) {
-    __shared__ float dz[CPB_ROWS][CPB_MAXH];
+                                                 float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, int T2, int H,
+                                                 float* __restrict__ part) {
+    __shared__ float dz[CPB_ROWS][HH];
     __shared__ float cy[CPB_ROWS], cx[CPB_ROWS];
     const int i0 = blockIdx.x * CPB_ROWS;
     const int nrow = min(CPB_ROWS, T2 - i0);
-    for (int e = threadIdx.x; e < CPB_ROWS * CPB_MAXH; e += 256) {
-        const int r = e / CPB_MAXH, h = e % CPB_MAXH;
+    for (int e = threadIdx.x; e < CPB_ROWS * HH; e += 256) {
+        const int r = e / HH, h = e % HH;
         float v = 0.f;
         if (r < nrow && h < H) {
             const float t = table16[(int64_t)(i0 + r) * H + h];
@@ -499,25 +526,53 @@ __global__ __launch_bounds__(256) void cpb_bwd_k(const float* __restrict__ coord
         cx[r] = r < nrow ? coords[2 * (i0 + r) + 1] : 0.f;
     }
     __syncthreads();
+    float* prow = part ? part + (size_t)blockIdx.x * (HH * 512 + 1536) : nullptr;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int j = threadIdx.x + half * 256;
-        float w2[CPB_MAXH], acc2[CPB_MAXH];
+        float w2[HH], acc2[HH];
 #pragma unroll
-        for (int h = 0; h < CPB_MAXH; ++h) { w2[h] = h < H ? W2[h * 512 + j] : 0.f; acc2[h] = 0.f; }
+        for (int h = 0; h < HH; ++h) { w2[h] = h < H ? W2[h * 512 + j] : 0.f; acc2[h] = 0.f; }
         float a0 = 0.f, a1 = 0.f, ab = 0.f;
-        for (int r = 0; r < nrow; ++r) {
-            const float hv = hidden[(int64_t)(i0 + r) * 512 + j];
+        float hv[CPB_ROWS];
+#pragma unroll
+        for (int r = 0; r < CPB_ROWS; ++r) hv[r] = hidden[(int64_t)min(i0 + r, T2 - 1) * 512 + j];      // all rows in flight at once
+#pragma unroll
+        for (int r = 0; r < CPB_ROWS; ++r) {
             float dh = 0.f;
 #pragma unroll
-            for (int h = 0; h < CPB_MAXH; ++h) { acc2[h] = fmaf(dz[r][h], hv, acc2[h]); dh = fmaf(dz[r][h], w2[h], dh); }
-            if (hv > 0.f) { a0 += dh * cy[r]; a1 += dh * cx[r]; ab += dh; }
+            for (int h = 0; h < HH; ++h) { acc2[h] = fmaf(dz[r][h], hv[r], acc2[h]); dh = fmaf(dz[r][h], w2[h], dh); }
+            if (hv[r] > 0.f) { a0 += dh * cy[r]; a1 += dh * cx[r]; ab += dh; }          // rows >= nrow carry dz = 0 -> dh = 0
         }
+        if (prow) {
 #pragma unroll
-        for (int h = 0; h < CPB_MAXH; ++h)
-            if (h < H) atomicAdd(dW2 + h * 512 + j, acc2[h]);
-        atomicAdd(dW1 + 2 * j, a0); atomicAdd(dW1 + 2 * j + 1, a1); atomicAdd(db1 + j, ab);
+            for (int h = 0; h < HH; ++h) prow[h * 512 + j] = acc2[h];
+            prow[HH * 512 + 2 * j] = a0; prow[HH * 512 + 2 * j + 1] = a1; prow[HH * 512 + 1024 + j] = ab;
+        } else {
+#pragma unroll
+            for (int h = 0; h < HH; ++h)
+                if (h < H) atomicAdd(dW2 + h * 512 + j, acc2[h]);
+            atomicAdd(dW1 + 2 * j, a0); atomicAdd(dW1 + 2 * j + 1, a1); atomicAdd(db1 + j, ab);
+        }
     }
+}
+// column sums of part [nblk][HH*512 + 1536] into dW2 [H*512] | dW1 [1024] | db1 [512]
+__global__ __launch_bounds__(256) void cpb_bwd_reduce_k(const float* __restrict__ part, int nblk, int HH, int H, float* __restrict__ dW1,
+                                                        float* __restrict__ db1, float* __restrict__ dW2) {
+    const int W = HH * 512 + 1536;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W) return;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;                 // blockIdx.y = slab of partial rows
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b < b1; b += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const float t = part[(size_t)min(b + u, nblk - 1) * W + c]; a[u] += (b + u < b1) ? t : 0.f; }
+    }
+    const float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (c < HH * 512) { if (c / 512 < H) atomicAdd(dW2 + c, v); }
+    else if (c < HH * 512 + 1024) atomicAdd(dW1 + c - HH * 512, v);
+    else atomicAdd(db1 + c - HH * 512 - 1024, v);
 }
 extern "C" int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden, float* table16,
                                    int T2, int H, hipStream_t stream) {
@@ -527,9 +582,15 @@ extern "C" int mvuld_cpb_table_fwd(const float* coords, const float* W1, const f
     return 0;
 }
 extern "C" int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16, const float* dtable16,
-                                   float* dW1, float* db1, float* dW2, int T2, int H, hipStream_t stream) {
+                                   float* dW1, float* db1, float* dW2, int T2, int H, float* ws, int64_t ws_bytes, hipStream_t stream) {
     MV_CHECK_ARG(coords && W2 && hidden && table16 && dtable16 && dW1 && db1 && dW2 && T2 > 0 && H > 0 && H <= CPB_MAXH, "cpb_table_bwd: bad args (H<=32)");
-    hipLaunchKernelGGL(cpb_bwd_k, dim3((unsigned)cdiv(T2, CPB_ROWS)), dim3(256), 0, stream, coords, W2, hidden, table16, dtable16, dW1, db1, dW2, T2, H);
+    const int nblk = (int)cdiv(T2, CPB_ROWS);
+    const int HH = H <= 4 ? 4 : (H <= 8 ? 8 : (H <= 16 ? 16 : 32));
+    float* part = (ws && ws_bytes >= (int64_t)nblk * (HH * 512 + 1536) * 4) ? ws : nullptr;
+#define CPB_BWD(HV) hipLaunchKernelGGL(cpb_bwd_k<HV>, dim3(nblk), dim3(256), 0, stream, coords, W2, hidden, table16, dtable16, dW1, db1, dW2, T2, H, part)
+    if (HH == 4) CPB_BWD(4); else if (HH == 8) CPB_BWD(8); else if (HH == 16) CPB_BWD(16); else CPB_BWD(32);
+#undef CPB_BWD
+    if (part) hipLaunchKernelGGL(cpb_bwd_reduce_k, dim3((unsigned)cdiv(HH * 512 + 1536, 256), 8), dim3(256), 0, stream, part, nblk, HH, H, dW1, db1, dW2);
     MV_LAUNCH_CHECK("cpb_table_bwd");
     return 0;
 }

@@ -295,9 +295,12 @@ def test_cpb_table(gpu):
     gc, gW1, gb1, gW2, gdt = dev(coords), dev(W1.data), dev(b1.data), dev(W2.data), dev(dt_)
     call("cpb_table_fwd", ptr(gc), ptr(gW1), ptr(gb1), ptr(gW2), ptr(hid), ptr(tab), T2, H)
     assert rel(tab, ref) < 1e-5
-    d1, db, d2 = torch.zeros(512, 2, device=gpu), torch.zeros(512, device=gpu), torch.zeros(H, 512, device=gpu)
-    call("cpb_table_bwd", ptr(gc), ptr(gW2), ptr(hid), ptr(tab), ptr(gdt), ptr(d1), ptr(db), ptr(d2), T2, H)
-    assert rel(d1, W1.grad) < 1e-4 and rel(db, b1.grad) < 1e-4 and rel(d2, W2.grad) < 1e-4
+    scratch = torch.empty(((T2 + 15) // 16) * (32 * 512 + 1536), device=gpu)
+    for ws_ in (None, scratch):             # atomics path, then per-block partials + reduce kernel
+        d1, db, d2 = torch.ones(512, 2, device=gpu), torch.ones(512, device=gpu), torch.ones(H, 512, device=gpu)
+        call("cpb_table_bwd", ptr(gc), ptr(gW2), ptr(hid), ptr(tab), ptr(gdt), ptr(d1), ptr(db), ptr(d2), T2, H,
+             ptr(ws_), ws_.numel() * 4 if ws_ is not None else 0)
+        assert rel(d1, W1.grad + 1) < 1e-4 and rel(db, b1.grad + 1) < 1e-4 and rel(d2, W2.grad + 1) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ graph
