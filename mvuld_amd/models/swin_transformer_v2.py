@@ -130,10 +130,15 @@ class _SwinBlockFn(torch.autograd.Function):
         call("cpb_table_bwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[2].weight), ptr(hidden), ptr(table16), ptr(dtable),
              ptr(ops.grad_of(a.cpb_mlp[0].weight)), ptr(ops.grad_of(a.cpb_mlp[0].bias)), ptr(ops.grad_of(a.cpb_mlp[2].weight)), T2, H,
              ptr(cws), cws.numel() * 4)
-        ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
         if a.q_bias is not None:
-            ops.colsum_into(dqkv, ops.grad_of(a.q_bias), N=C, col0=0)
-            ops.colsum_into(dqkv, ops.grad_of(a.v_bias), N=C, col0=2 * C)
+            # q_bias / v_bias gradients = column sums of dqkv: taken from the weight-gradient kernel's fused column sum (one
+            # [3C] scratch, two slice adds) instead of two more passes over dqkv
+            dqb = torch.zeros(3 * C, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad(dqkv, x, a.qkv.weight, None, bias_out=dqb)
+            ops.grad_of(a.q_bias).add_(dqb[:C])
+            ops.grad_of(a.v_bias).add_(dqb[2 * C:])
+        else:
+            ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
         dx = ops.gemm_nt(dqkv, ops.weight_t(a.qkv.weight, ad), epi=hip.EPI_ADD_AUX, aux=g1)
         return dx, None, None
 

@@ -180,8 +180,10 @@ def wgrad_splitk(n_out, k_out, depth):
     return int(max(1, min(want, ktiles // 4 if ktiles >= 8 else 1)))
 
 
-def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
-    """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers."""
+def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers.
+    bias_out: an fp32 [N] buffer to accumulate colsum(dy) into instead of b_param.grad (returns False if the path taken
+    could not fuse it, so the caller falls back to explicit column sums)."""
     M, N = dy.shape
     K = x.shape[1]
     if (w_param is not None and dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dyT is None and not FORCE_SIMPLE_GEMM[0]
@@ -194,9 +196,12 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None):
         splitk = sk1 if (f1 >= 0.9 or f2 <= f1 + 0.05) else sk2
         splitk = max(1, min(math.ceil(M / 64 / 4), splitk))
         hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
+        bias_dst = bias_out if bias_out is not None else (grad_of(b_param) if b_param is not None else None)
         call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(grad_of(w_param)), K, M, N, K,
-             ptr(grad_of(b_param)) if b_param is not None else None, splitk)
-        return
+             ptr(bias_dst), splitk)
+        return True
+    if bias_out is not None:
+        colsum_into(dy, bias_out)
     if b_param is not None:
         colsum_into(dy, grad_of(b_param))
     if w_param is None:
