@@ -74,6 +74,7 @@ int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float*
 /* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta accumulate (+=).  `ws` (optional, fp32,
  * ws_bytes >= 512*C) lends room for per-block column partials summed by a second kernel; without it the column sums
  * are device atomics (slower: ~1.5M contended atomics per launch at C=768). */
+int64_t mvuld_layernorm_bwd_workspace_bytes(int C);   /* size of `ws` for the two-pass column sums */
 int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                         const float* rowscale, int rows_per_sample, void* dx, float* dgamma, float* dbeta,
                         int64_t rows, int C, float* ws, int64_t ws_bytes, int dtype, mvuld_stream_t stream);
@@ -109,6 +110,7 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
 int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         void* out, float* lse, int dtype, mvuld_stream_t stream);
+int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, int nW, int ws);   /* size of `ws_part` */
 int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
@@ -118,6 +120,7 @@ int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, 
 /* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,
                         float* table16, int T2, int H, mvuld_stream_t stream);
+int64_t mvuld_cpb_table_bwd_workspace_bytes(int T2, int H);   /* size of `ws` */
 int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16,
                         const float* dtable16, float* dW1, float* db1, float* dW2, int T2, int H,
                         float* ws, int64_t ws_bytes, mvuld_stream_t stream);     /* ws (optional): >= ceil(T2/16)*(32*512+1536)*4 bytes of

@@ -937,6 +937,13 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
 }
 
 // workspaces (caller-owned): delta [tokens * H] fp32; qt [tokens, H*hd] bf16 (MODE 0: normalised, scaled queries).  dqkv is fully written.
+/* bytes of fp32 scratch (ws_part) the bias-table gradient pass of mvuld_attn_bwd_mfma wants: one (2ws-1)^2 table per workgroup */
+extern "C" int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, int nW, int ws) {
+    if (mode != 0) return 0;
+    const int64_t groups = (int64_t)B * nW * H;
+    const int64_t T2 = (int64_t)(2 * ws - 1) * (2 * ws - 1);
+    return (groups > 512 ? groups : 512) * T2 * 4;          // the pass splits small grids up to < 512 workgroups
+}
 extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,

@@ -581,6 +581,11 @@ extern "C" int mvuld_cpb_table_fwd(const float* coords, const float* W1, const f
     MV_LAUNCH_CHECK("cpb_table_fwd");
     return 0;
 }
+/* bytes of fp32 scratch mvuld_cpb_table_bwd wants (one row of HH*512+1536 partial sums per block of CPB_ROWS table rows) */
+extern "C" int64_t mvuld_cpb_table_bwd_workspace_bytes(int T2, int H) {
+    const int HH = H <= 4 ? 4 : (H <= 8 ? 8 : (H <= 16 ? 16 : 32));
+    return (int64_t)cdiv(T2 > 0 ? T2 : 0, CPB_ROWS) * (HH * 512 + 1536) * 4;
+}
 extern "C" int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16, const float* dtable16,
                                    float* dW1, float* db1, float* dW2, int T2, int H, float* ws, int64_t ws_bytes, hipStream_t stream) {
     MV_CHECK_ARG(coords && W2 && hidden && table16 && dtable16 && dW1 && db1 && dW2 && T2 > 0 && H > 0 && H <= CPB_MAXH, "cpb_table_bwd: bad args (H<=32)");

@@ -508,3 +508,7 @@ extern "C" int mvuld_batchnorm_bwd(const void* dy, const void* x, const float* g
     MV_LAUNCH_CHECK("batchnorm_bwd");
     return 0;
 }
+
+/* bytes of fp32 scratch mvuld_layernorm_bwd wants for its two-pass column sums (1024 blocks x 2C floats) */
+extern "C" int64_t mvuld_layernorm_bwd_workspace_bytes(int C) { return (int64_t)1024 * 2 * (C > 0 ? C : 0) * 4; }
+

@@ -29,7 +29,7 @@ def parse_header(path=HEADER_PATH):
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(mvuld_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(mvuld_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -40,7 +40,7 @@ def parse_header(path=HEADER_PATH):
                 else:
                     base = a.replace("const ", "").split(" ")[0]
                     argtypes.append(_CT[base])
-        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, argtypes)
+        protos[name] = (ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int), argtypes)
     return protos
 
 

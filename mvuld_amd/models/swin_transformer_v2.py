@@ -126,7 +126,7 @@ class _SwinBlockFn(torch.autograd.Function):
         dtable = torch.zeros((T2, H), dtype=torch.float32, device=x.device)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
                             ops.grad_of(a.logit_scale).view(-1))
-        cws = ops._workspace(x.device, ((T2 + 15) // 16) * (32 * 512 + 1536) * 4)
+        cws = ops._workspace(x.device, hip.LIB.fn("mvuld_cpb_table_bwd_workspace_bytes")(T2, H))
         call("cpb_table_bwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[2].weight), ptr(hidden), ptr(table16), ptr(dtable),
              ptr(ops.grad_of(a.cpb_mlp[0].weight)), ptr(ops.grad_of(a.cpb_mlp[0].bias)), ptr(ops.grad_of(a.cpb_mlp[2].weight)), T2, H,
              ptr(cws), cws.numel() * 4)

@@ -238,7 +238,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_p
 def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sample=1):
     rows, C = x.shape
     dx = torch.empty_like(x)
-    ws = _workspace(x.device, 8 * 1024 * 1024)
+    ws = _workspace(x.device, hip.LIB.fn("mvuld_layernorm_bwd_workspace_bytes")(C))
     call("layernorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(rowscale), rows_per_sample, ptr(dx),
          ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)), rows, C, ptr(ws), ws.numel() * 4, dt(x))
     return dx
@@ -330,7 +330,7 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
         part = None
         if g.mode == 0:
-            part = _workspace(qkv.device, max(g.B * g.nW * g.H, 512) * (2 * g.ws - 1) ** 2 * 4)     # one table per workgroup
+            part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))     # one table per workgroup
         call("attn_bwd_mfma", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
              ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt), ptr(part), part.numel() * 4 if part is not None else 0,
              dt(qkv))
