@@ -733,6 +733,184 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
     }
 }
 
+// ------------------------------------------------------------------------------------ MFMA bf16, 256 x 128 tile, 3-stage LDS-DMA ring
+// gemm_nt_mfma_bf16_ring128 with twice the rows: 8 waves (4 x 2) x (64 x 64), three 32-deep stages of 24 KiB (72 KiB: two
+// workgroups = 16 waves per CU), 85 instead of 64 FLOP per L2 byte.  K % 32 == 0.
+#define G4_BM 256
+#define G4_STAGE_BYTES 24576        // A 256 x 32 bf16 (16 KiB) + B 128 x 32 bf16 (8 KiB)
+#define G4_LDS_BYTES (3 * G4_STAGE_BYTES)
+
+template <typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;        // 4 x 2 waves
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nt = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nt >> 3, r = nt & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * G4_BM, n0 = tn * GT_BN;
+    const int b = blockIdx.y;
+    const bf16* A = (const bf16*)g.A + (int64_t)b * g.sA;
+    const bf16* B = (const bf16*)g.B + (int64_t)b * g.sB;
+    TO* C = (TO*)g.C + (int64_t)b * g.sC;
+    TO* aux = g.aux ? (TO*)g.aux + (int64_t)b * g.sAux : nullptr;
+    const int nk = g.K / G2_BK;
+
+    // LDS-DMA map: pieces of 1 KiB (16 rows); wave w issues pieces 2w, 2w+1 of the A tile (16 pieces) and piece w of the B tile (8)
+    const bf16* ga[2];
+    const bf16* gb;
+    {
+        const int chs = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 16 + (lane >> 2);
+            ga[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (chs ^ ((4 - ((row >> 2) & 3)) & 3)) * 8;
+        }
+        const int rowb = wave * 16 + (lane >> 2);
+        gb = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb + (chs ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 8;
+    }
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % 3) * G4_STAGE_BYTES;
+        const int k0 = kt * G2_BK;
+        __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + (wave * 2) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave * 2 + 1) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_vp)(gb + k0), (lds_vp)(st + 16384 + wave * 1024), 16, 0, 0);
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int oa[4], ob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oa[i] = g2_off(wr * 64 + i * 16 + fr, fg);
+        ob[i] = 16384 + g2_off(wc * 64 + i * 16 + fr, fg);
+    }
+    if (0 < nk) issue(0);
+    if (1 < nk) issue(1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most the one younger tile (3 loads) is still in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // tile kt visible to everyone; everyone is done with tile kt-1
+        if (kt + 2 < nk) issue(kt + 2);          // refills the stage tile kt-1 occupied
+        const char* st = smem + stage * G4_STAGE_BYTES;
+        stage = stage == 2 ? 0 : stage + 1;
+        bf16x8_t fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = *(const bf16x8_t*)(st + ob[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue (as gemm_nt_mfma_bf16<TO, 1>): two 32-row halves of the wave's 64 x 64 block through a per-wave fp32 LDS tile
+    float* ep = (float*)(smem + wave * (32 * GT_EPI_LD * 4));
+    const int lc = (lane & 7) * 8;
+    const int col = n0 + wc * 64 + lc;
+    const bool vec_ok = (g.out_mode == OUT_STORE) && (g.N % 8 == 0) && (g.ldc % 8 == 0) && (g.epi < EPI_GELU || (g.ldaux % 8 == 0));
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = g.bias[min(col + e, g.N - 1)];
+            bias8[e] = (col + e < g.N) ? t : 0.f;
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[qt * 2 + i][j][r];
+        __syncthreads();
+#pragma unroll 2
+        for (int p = 0; p < 4; ++p) {
+            const int lr = p * 8 + (lane >> 3);
+            const int row = m0 + wr * 64 + qt * 32 + lr;
+            const bool valid = row < g.M && col < g.N;
+            const float4 va = *(const float4*)(ep + lr * GT_EPI_LD + lc);
+            const float4 vb = *(const float4*)(ep + lr * GT_EPI_LD + lc + 4);
+            float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+            if (vec_ok) {
+                float ax[8];
+                if (g.epi >= EPI_MUL_DGELU) {
+                    const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
+                    if constexpr (sizeof(TO) == 4) {
+                        const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
+                        ax[0] = a0.x; ax[1] = a0.y; ax[2] = a0.z; ax[3] = a0.w; ax[4] = a1.x; ax[5] = a1.y; ax[6] = a1.z; ax[7] = a1.w;
+                    } else {
+                        const bf16x8 a = *(const bf16x8*)ap;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ax[e] = (float)a.v[e];
+                    }
+                }
+                float pre[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = g.alpha * v[e] + bias8[e];
+                    pre[e] = x;
+                    switch (g.epi) {
+                        case EPI_GELU: x = gelu_erf(x); break;
+                        case EPI_ELU: x = elu1(x); break;
+                        case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                        case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
+                        case EPI_ADD_AUX: x += ax[e]; break;
+                        default: break;
+                    }
+                    v[e] = x;
+                }
+                if (!valid) continue;
+                TO* cp = C + (int64_t)row * g.ldc + col;
+                if constexpr (sizeof(TO) == 4) {
+                    *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (g.epi == EPI_GELU && aux) {
+                        float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
+                        *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
+                        *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+                    }
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
+                    *(bf16x8*)cp = o;
+                    if (g.epi == EPI_GELU && aux) {
+                        bf16x8 q;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
+                        *(bf16x8*)(aux + (int64_t)row * g.ldaux + col) = q;
+                    }
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (col + e < g.N) epilogue_store<TO>(g, C, aux, row, col + e, v[e]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ MFMA bf16, "TN": weight gradients
 // C[N,K] (+)= sum_m A[m,n] * B[m,k]   with A = dY [M,N] and B = X [M,K] in their natural row-major (token-major) layout.
 // Both operands need 8 consecutive m per (n|k) column for the matrix cores, i.e. a transposed fragment: the tiles are
@@ -934,6 +1112,23 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
         // 128 x 128 LDS-DMA ring for contractions up to MVULD_GEMM_RING_MAXK (default 2304; 0 = never): +8..15 % on the short-K
         // shapes (two tiles always in flight instead of one burst of loads per k-step); the register-staged loop below keeps the
         // long-K ones (K = 3072 / 4096: 10-15 % better there, its 64-deep steps halve the barriers per FLOP).
+        // 256 x 128 LDS-DMA ring (two 8-wave workgroups / CU, 85 FLOP per L2 byte) whenever the taller tiles still fill the chip:
+        // 3-15 % over the 128 x 128 ring on every shape of the step, -1.8 ms per step.  MVULD_GEMM_RING256X128 = minimum K (0 = off).
+        static int ring4 = -1;
+        if (ring4 < 0) { const char* e = getenv("MVULD_GEMM_RING256X128"); ring4 = e ? atoi(e) : 32; }
+        if (ring4 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= ring4 && (int64_t)cdiv(M, G4_BM) * tiles_n * batch >= 256) {
+            const int tm4 = (int)cdiv(M, G4_BM);
+            static bool attr4 = false;
+            if (!attr4) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring256x128<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring256x128<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
+                attr4 = true;
+            }
+            if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring256x128<float>), dim3(tm4 * tiles_n, batch), dim3(512), G4_LDS_BYTES, stream, g, tm4, tiles_n);
+            else hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring256x128<bf16>), dim3(tm4 * tiles_n, batch), dim3(512), G4_LDS_BYTES, stream, g, tm4, tiles_n);
+            MV_LAUNCH_CHECK("gemm_nt_mfma_bf16_ring256x128");
+            return 0;
+        }
         static int ring = -1;
         if (ring < 0) { const char* e = getenv("MVULD_GEMM_RING_MAXK"); ring = e ? atoi(e) : 2304; }
         if (splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K <= ring) {
