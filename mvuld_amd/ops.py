@@ -186,6 +186,18 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
     could not fuse it, so the caller falls back to explicit column sums)."""
     M, N = dy.shape
     K = x.shape[1]
+    if (w_param is not None and dy.dtype == torch.float32 and x.dtype == torch.float32 and USE_SPLIT3[0] and USE_TN_WGRAD[0]
+            and not FORCE_SIMPLE_GEMM[0] and N % 8 == 0 and K % 8 == 0 and M >= 64 and dy.is_contiguous() and x.is_contiguous()):
+        # fp32 tail of a bf16 model: its weight gradients are formed like every other weight gradient of the model, from
+        # bf16-rounded operands with fp32 accumulation, through the transpose-free kernel (the fp32 route costs two transposes,
+        # two 3-term splits and a 3x longer product per weight)
+        # (the bias gradient stays an fp32 column sum: behind a BatchNorm it is a sum of terms that cancel to ~0)
+        if bias_out is not None:
+            colsum_into(dy, bias_out)
+        elif b_param is not None:
+            colsum_into(dy, grad_of(b_param))
+        bias_out, b_param = None, None
+        dy, x, dyT, xT = cast(dy, torch.bfloat16), cast(x, torch.bfloat16), None, None
     if (w_param is not None and dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dyT is None and not FORCE_SIMPLE_GEMM[0]
             and USE_TN_WGRAD[0]):
         tiles = math.ceil(N / 128) * math.ceil(K / 128)
