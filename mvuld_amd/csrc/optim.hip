@@ -26,18 +26,46 @@ __global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, flo
     norm_out[1] = grad_scale * (max_norm > 0.f ? fminf(1.0f, max_norm / (n + 1e-6f)) : 1.0f);
 }
 
-__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// 16-byte accesses (the flat store pads every tensor to 64 elements); zero_grad != 0 also clears the gradient it has just consumed,
+// which replaces the separate zero_grad() fill pass over the 0.9 GB buffer.
+__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                bf16* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                               float bc1, float bc2_sqrt, const float* __restrict__ coef) {
+                                               float bc1, float bc2_sqrt, const float* __restrict__ coef, int zero_grad) {
     const float c = coef ? coef[1] : 1.0f;
     const float step = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float decay = 1.0f - lr * wd;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 g4 = ((const float4*)g)[i];
+        float4 p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
+        float gg[4] = {g4.x * c, g4.y * c, g4.z * c, g4.w * c};
+        float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gg[e];
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+            pp[e] = pp[e] * decay - step * mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+        }
+        ((float4*)p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        ((float4*)m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        ((float4*)v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p16) {
+            union { uint2 u; bf16 e[4]; } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.e[e] = (bf16)pp[e];
+            ((uint2*)p16)[i] = o.u;
+        }
+    }
+    // tail (n not a multiple of 4)
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * c;
-        float pi = p[i] * (1.0f - lr * wd);
+        float pi = p[i] * decay;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;
         if (p16) p16[i] = (bf16)pi;
     }
 }
@@ -55,13 +83,14 @@ extern "C" int mvuld_clip_coef(const float* sumsq, float max_norm, float grad_sc
     MV_LAUNCH_CHECK("clip_coef");
     return 0;
 }
-extern "C" int mvuld_adamw(float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int step, const float* coef, hipStream_t stream) {
+extern "C" int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int step, const float* coef, int zero_grad, hipStream_t stream) {
     MV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+    MV_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p16) & 7) == 0, "adamw: buffers must be 16-byte aligned");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
-    hipLaunchKernelGGL(adamw_k, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, coef);
+    const int grid = (int)min((int64_t)8192, cdiv(n, 1024));
+    hipLaunchKernelGGL(adamw_k, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, coef, zero_grad);
     MV_LAUNCH_CHECK("adamw");
     return 0;
 }

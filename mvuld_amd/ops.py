@@ -108,6 +108,9 @@ def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
     """fp32 gradient buffer of a parameter (atomic-accumulate target)."""
     if p.grad is None:
         p.grad = torch.zeros_like(p.data, dtype=torch.float32)
+    st = getattr(p, "_mv_store", None)
+    if st is not None:
+        st.grads_zeroed = False           # something is about to accumulate: the next zero_grad() must really clear
     return p.grad
 
 

@@ -87,6 +87,9 @@ class ParamStore:
         return out
 
     def zero_grad(self):
+        if getattr(self, "grads_zeroed", False):      # FusedAdamW.step already cleared the buffer
+            self.grads_zeroed = False
+            return
         self.grad.zero_()
 
     def clip_grad_norm_(self, max_norm, grad_scale=None):
@@ -124,7 +127,8 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = grp["betas"]
             call("adamw", st.flat.data_ptr() + 4 * a, st.grad.data_ptr() + 4 * a, st.exp_avg.data_ptr() + 4 * a,
                  st.exp_avg_sq.data_ptr() + 4 * a, st.flat16.data_ptr() + 2 * a, b - a, float(grp["lr"]), float(b1), float(b2),
-                 float(grp["eps"]), float(grp["weight_decay"]), self._step, ptr(coef))
+                 float(grp["eps"]), float(grp["weight_decay"]), self._step, ptr(coef), 1)
+        st.grads_zeroed = True            # the kernel cleared every gradient it consumed: the zero_grad() after this step is free
         self._clipped = False
         ops.bump_weight_epoch()           # transposed weight copies are stale now: refresh the registered ones together
         ops.refresh_store_transposes(st)
