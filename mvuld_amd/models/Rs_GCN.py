@@ -71,7 +71,8 @@ class _RsGCNFn(torch.autograd.Function):
         dph = torch.empty_like(ph)
         ops.gemm_nt(dR, phT, out=dth, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
         ops.gemm_nt(dRT, thT, out=dph, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
-        vT = ops.transpose(v)
+        # the transposed input is only an operand of the fp32 (parity-mode) weight-gradient route
+        vT = None if (ops.USE_SPLIT3[0] and ops.USE_TN_WGRAD[0] and not ops.FORCE_SIMPLE_GEMM[0]) else ops.transpose(v)
         ops.linear_wgrad(dth, v, mod.theta.weight, mod.theta.bias, xT=vT)
         ops.linear_wgrad(dph, v, mod.phi.weight, mod.phi.bias, xT=vT)
         ops.linear_wgrad(dgv, v, mod.g.weight, mod.g.bias, xT=vT)
