@@ -140,6 +140,9 @@ class _SwinBlockFn(torch.autograd.Function):
         else:
             ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
         dx = ops.gemm_nt(dqkv, ops.weight_t(a.qkv.weight, ad), epi=hip.EPI_ADD_AUX, aux=g1)
+        tag = getattr(blk, "_backward_done_tag", None)
+        if tag is not None:
+            ops.fire_backward_done(tag)     # first block of its stage: the stage's gradients (blocks + downsample) are final
         return dx, None, None
 
 
@@ -370,8 +373,9 @@ class SwinTransformerV2(nn.Module):
         self.norm = nn.LayerNorm(self.num_features)
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.apply(self._init_weights)
-        for bly in self.layers:
+        for i, bly in enumerate(self.layers):
             bly._init_respostnorm()
+            bly.blocks[0]._backward_done_tag = f"swin.layers.{i}"      # fired when stage i's backward has launched its last kernel
         self._dp_gen = torch.Generator().manual_seed(0)
 
     def _init_weights(self, m):

@@ -186,6 +186,14 @@ def test_param_groups_and_flat_store_on_cpu():
         assert p.grad is not None and p.grad.shape == p.shape and torch.equal(p._mv_w16.float(), before[n].bfloat16().float())
     seg = st.segment("layers.0.")
     assert seg and all(b > a for a, b in seg)
+    # per-stage ranges (what the per-stage gradient all-reduce launches): pairwise disjoint, and each holds exactly its stage
+    stages = [st.segment(f"layers.{i}.") for i in range(4)]
+    flat = sorted(r for sg in stages for r in sg)
+    assert all(flat[i][1] <= flat[i + 1][0] for i in range(len(flat) - 1))
+    for i, sg in enumerate(stages):
+        own = sum(((n + 63) // 64) * 64 for name, _, _, n, _ in st.layout if name.startswith(f"layers.{i}."))
+        assert sum(b - a for a, b in sg) == own
+    assert getattr(m.layers[2].blocks[0], "_backward_done_tag") == "swin.layers.2"
     st.grad.fill_(1.0); st.zero_grad()
     assert float(st.grad.abs().sum()) == 0.0
 
