@@ -182,7 +182,9 @@ int mvuld_segment_pad_bwd(const void* dout, const int* node_offsets, void* dh, i
                           int dtype, mvuld_stream_t stream);
 
 /* clip_grad_norm_(5.0) + AdamW: utils_multi.py:229-232, optimizer.py:27-31 */
-int mvuld_sumsq(const float* x, int64_t n, float* out, mvuld_stream_t stream);
+/* out[0] += sum x^2, bit-reproducible (no float atomics: every data-parallel rank must get the same clip coefficient);
+ * partials = caller-owned scratch of >= 2048 floats */
+int mvuld_sumsq(const float* x, int64_t n, float* partials, float* out, mvuld_stream_t stream);
 int mvuld_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* norm_out, mvuld_stream_t stream);
 int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, const float* coef, int zero_grad, mvuld_stream_t stream);

@@ -4,7 +4,11 @@
 // which also refreshes the bf16 working copy the MFMA GEMMs read.  ~28 B/param/step, HBM-bound.
 #include "common.h"
 
-__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// Deterministic: every rank must derive the SAME clip coefficient from the same all-reduced gradient, or the replicas drift
+// apart (nothing re-synchronises parameters in data-parallel training).  So no float atomics here: fixed grid, fixed per-thread
+// order, one partial per block, and a single block folds the partials in a fixed tree.
+#define SUMSQ_MAX_BLOCKS 2048
+__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int64_t n, float* __restrict__ partials) {
     __shared__ float red[16];
     float s = 0.f;
     const int64_t n4 = n >> 2;
@@ -15,7 +19,14 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int6
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i] * x[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_k(const float* __restrict__ partials, int nblk, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] += s;
 }
 
 // The buffer holds grad_scale^-1 times the true gradient (sum over ranks: grad_scale = 1/world).
@@ -70,10 +81,11 @@ __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, float* __r
     }
 }
 
-extern "C" int mvuld_sumsq(const float* x, int64_t n, float* out, hipStream_t stream) {
-    MV_CHECK_ARG(x && out && n > 0 && (((uintptr_t)x & 15) == 0), "sumsq: bad args (16-byte aligned fp32 buffer)");
-    const int grid = (int)min((int64_t)2048, cdiv(n, 1024));
-    hipLaunchKernelGGL(sumsq_k, dim3(grid), dim3(256), 0, stream, x, n, out);
+extern "C" int mvuld_sumsq(const float* x, int64_t n, float* partials, float* out, hipStream_t stream) {
+    MV_CHECK_ARG(x && partials && out && n > 0 && (((uintptr_t)x & 15) == 0), "sumsq: bad args (16-byte aligned fp32 buffer, 2048-float scratch)");
+    const int grid = (int)min((int64_t)SUMSQ_MAX_BLOCKS, cdiv(n, 1024));
+    hipLaunchKernelGGL(sumsq_k, dim3(grid), dim3(256), 0, stream, x, n, partials);
+    hipLaunchKernelGGL(sumsq_final_k, dim3(1), dim3(256), 0, stream, partials, grid, out);
     MV_LAUNCH_CHECK("sumsq");
     return 0;
 }

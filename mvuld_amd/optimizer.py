@@ -57,6 +57,7 @@ class ParamStore:
         self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.norm = torch.zeros(2, dtype=torch.float32, device=device)      # [grad norm, clip coefficient]
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self._sumsq_partials = torch.zeros(2048, dtype=torch.float32, device=device)
         self.grad_scale = 1.0
         for name, p, o, n, _ in self.layout:
             self.flat[o:o + n].copy_(p.data.reshape(-1).to(device))
@@ -99,7 +100,7 @@ class ParamStore:
         if grad_scale is None:
             grad_scale = self.grad_scale
         self._sumsq.zero_()
-        call("sumsq", ptr(self.grad), self.total, ptr(self._sumsq))
+        call("sumsq", ptr(self.grad), self.total, ptr(self._sumsq_partials), ptr(self._sumsq))
         call("clip_coef", ptr(self._sumsq), float(max_norm) if max_norm else 0.0, float(grad_scale), ptr(self.norm))
         return self.norm[0]
 

@@ -395,7 +395,13 @@ def test_cross_entropy_adamw_sumsq(gpu):
     M_, V_ = torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
     P16 = torch.empty(n, dtype=torch.bfloat16, device=gpu)
     ss = torch.zeros(1, device=gpu); no = torch.zeros(2, device=gpu)
-    call("sumsq", ptr(G), n, ptr(ss))
+    part = torch.empty(2048, device=gpu)
+    call("sumsq", ptr(G), n, ptr(part), ptr(ss))
+    big = torch.randn(3_000_001, device=gpu)                   # bit-reproducible: data-parallel ranks must agree on the clip coefficient
+    r = [torch.zeros(1, device=gpu) for _ in range(3)]
+    for ri in r:
+        call("sumsq", ptr(big), big.numel(), ptr(part), ptr(ri))
+    assert float(r[0]) == float(r[1]) == float(r[2]) and rel(r[0], (big.double() ** 2).sum().float()) < 1e-5
     assert rel(ss, (g0 ** 2).sum()) < 1e-5
     call("clip_coef", ptr(ss), float(g0.norm() * 0.5), 1.0, ptr(no))
     for step in (1, 2, 3):
