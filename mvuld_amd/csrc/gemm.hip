@@ -658,14 +658,17 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        __syncthreads();
+        // the staging tile is private to the wave: one workgroup barrier (everyone is done reading the last stage), after that
+        // only wave-level ordering (LDS instructions of a wave execute in order)
+        if (qt == 0) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[qt * 2 + i][j][r];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
         for (int p = 0; p < 4; ++p) {
             const int lr = p * 8 + (lane >> 3);
@@ -836,14 +839,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        __syncthreads();
+        // the staging tile is private to the wave: one workgroup barrier (everyone is done reading the last stage), after that
+        // only wave-level ordering (LDS instructions of a wave execute in order)
+        if (qt == 0) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[qt * 2 + i][j][r];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
         for (int p = 0; p < 4; ++p) {
             const int lr = p * 8 + (lane >> 3);
