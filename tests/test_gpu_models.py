@@ -1,6 +1,7 @@
 """GPU parity of the three modules and the fused model against the CPU oracle / committed goldens.
 
 Tolerances follow BASELINE.json's north_star: logits within 1e-3 (fp32) / 1e-2 (bf16) of the reference."""
+import os
 import types
 
 import numpy as np
@@ -395,3 +396,21 @@ def test_fused_two_stream_matches_single_stream(gpu, monkeypatch):
         assert float((g0 - g1).norm() / g0.norm()) < 1e-4
         assert int((g1 != 0).sum()) == int((g0 != 0).sum())
 
+
+
+def test_main_bigvul_cli_end_to_end(gpu, tmp_path):
+    """The reference's entry point end to end on the plumbing-size config: `main_bigvul.py --cfg ... --batch-size B` trains one
+    short epoch (train_one_epoch: fused step + cosine LR), validates (P / R / F1 / PR-AUC on synthetic labels), writes the
+    reference's checkpoint layout, and `--test 1` evaluates the test split with the same code path (main_bigvul.py:294-500)."""
+    from mvuld_amd import main_bigvul
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    out, mout = str(tmp_path / "out"), str(tmp_path / "multi")
+    common = ["--cfg", cfg, "--batch-size", "2", "--output", out, "--max-steps", "3",
+              "--opts", "TRAIN.EPOCHS", "1", "FUSED.SYNTH_TRAIN", "8", "FUSED.SYNTH_VAL", "4", "FUSED.SYNTH_TEST", "4", "MULTI_OUTPUT", mout,
+              "TRAIN.AUTO_RESUME", "False", "DATA.NUM_WORKERS", "0"]
+    model = main_bigvul.main(common)
+    flat = model._mv_store.flat
+    assert bool(torch.isfinite(flat).all())
+    log = "".join(open(os.path.join(dp, f)).read() for dp, _, fs in os.walk(out) for f in fs if f.startswith("log"))
+    assert "Start training" in log and "Train: [0/1]" in log and "Max accuracy" in log
+    main_bigvul.main(common + ["--test", "1"])
