@@ -443,3 +443,27 @@ def test_fused_full_size_eval_logits_vs_oracle(gpu, dtype):
     err = float((logits - ref).abs().max())
     print(f"[fused full size, {dtype} eval] logits abs err {err:.3e} (logit scale {float(ref.abs().max()):.3f})")
     assert err < (1e-3 if dtype == torch.float32 else 1e-2)
+
+
+def test_fused_full_size_batch_permutation_property(gpu):
+    """Size-independent property at the full model size: every function's logits depend only on that function (eval mode: running
+    BatchNorm statistics, no dropout), so reversing the order of a batch of 8 -- different image rows, token rows, graph node ranges,
+    GEMM tiles and attention workgroups for every function -- must reverse the logits and nothing else."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16"], batch_size=8, local_rank=0))
+    model = build_fused_model(config)
+    load_synth_into(model)
+    model = model.to(gpu).eval()
+    f = config.FUSED
+    idx = [41, 42, 43, 44, 45, 46, 47, 48]
+    outs = []
+    with torch.no_grad():
+        for order in (idx, idx[::-1]):
+            g, images, ids, _ = synthetic.make_batch(order, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+            outs.append(model(g.to(gpu), images.to(gpu), ids.to(gpu)).float().cpu())
+    assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].std()) > 0
+    assert float((outs[0] - outs[1].flip(0)).abs().max()) < 1e-4
