@@ -1,6 +1,7 @@
 """GPU parity of the three modules and the fused model against the CPU oracle / committed goldens.
 
 Tolerances follow BASELINE.json's north_star: logits within 1e-3 (fp32) / 1e-2 (bf16) of the reference."""
+import math
 import os
 import types
 
@@ -467,3 +468,34 @@ def test_fused_full_size_batch_permutation_property(gpu):
             outs.append(model(g.to(gpu), images.to(gpu), ids.to(gpu)).float().cpu())
     assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].std()) > 0
     assert float((outs[0] - outs[1].flip(0)).abs().max()) < 1e-4
+
+
+def test_fused_full_size_train_steps_reduce_loss(gpu):
+    """Size-independent property of the whole train step at full model size (bf16, two streams, fused AdamW): six steps on one fixed
+    batch of 8 functions must drive the cross-entropy down from ln 2 -- forward, every backward kernel, the gradient clip and the
+    optimizer have to agree on signs and scales for that to happen."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16", "TRAIN.BASE_LR", "1e-4"], batch_size=8, local_rank=0))
+    torch.manual_seed(3)
+    model = build_fused_model(config).to(gpu).train()
+    opt = build_optimizer(config, model)
+    f = config.FUSED
+    g, images, ids, labels = synthetic.make_batch(list(range(60, 68)), config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g, images, ids, labels = g.to(gpu), images.to(gpu), ids.to(gpu), labels.to(gpu)
+    losses = []
+    for _ in range(6):
+        loss, _ = cross_entropy(model(g, images, ids), labels)
+        loss.backward()
+        norm = opt.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
+    print("[full-size train] losses", [round(x, 4) for x in losses])
+    assert losses[-1] < losses[0] - 0.03 and min(losses) == min(losses[3:])
