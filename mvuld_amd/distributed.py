@@ -82,6 +82,9 @@ class GradAllReducer:
         ws = world_size()
         if ws == 1:
             return
+        if self.g.is_cuda:
+            from . import ops
+            ops.join_wgrad_stream()           # gradients still being accumulated on the weight-gradient stream
         covered = sorted(self.done)
         pos = 0
         for a, b in covered + [(self.g.numel(), self.g.numel())]:

@@ -27,6 +27,7 @@ class FusedMVulD(nn.Module):
             p.requires_grad_(False)
         self.head = Multi_DefectModel_new_GCN(config, act_dtype=act_dtype)
         self._side = None
+        self._wg = None
         for n, p in self.head.named_parameters():
             if n.startswith(self.head.unused_parameter_prefixes):
                 p.requires_grad_(False)
@@ -46,6 +47,7 @@ class FusedMVulD(nn.Module):
         from .. import hip, ops
         concurrent = images.is_cuda and os.environ.get("MVULD_CONCURRENT", "1") != "0" and not hip.TIMING.enabled
         if not concurrent:
+            ops.WGRAD_STREAM[0] = None
             ops.on_backward_done("unixcoder", None, key="fused-join")
             img = self.swin.forward_features(images)                   # [B,1024]
             _, txt = self.unixcoder.get_xcode_vec(source_ids)          # [B,768]
@@ -55,6 +57,12 @@ class FusedMVulD(nn.Module):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=images.device)
             side = self._side
+            if self._wg is None:
+                self._wg = torch.cuda.Stream(device=images.device)
+            # third stream: the image encoder's weight gradients (nothing in backward depends on them); joined into the main
+            # stream when the encoder's first op has finished its backward (ops.fire_backward_done("swin"))
+            use_wg = torch.is_grad_enabled() and self.training and os.environ.get("MVULD_WGRAD_STREAM", "1") != "0"
+            ops.WGRAD_STREAM[0] = (main.cuda_stream, self._wg) if use_wg else None
             side.wait_stream(main)
             # Side stream: the text encoder and the head's graph branch (which needs neither encoder: many small launches
             # that leave most of the chip idle), both under the image encoder's dense kernels on the main stream.  Host

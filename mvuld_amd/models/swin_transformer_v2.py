@@ -134,9 +134,10 @@ class _SwinBlockFn(torch.autograd.Function):
             # q_bias / v_bias gradients = column sums of dqkv: taken from the weight-gradient kernel's fused column sum (one
             # [3C] scratch, two slice adds) instead of two more passes over dqkv
             dqb = torch.zeros(3 * C, dtype=torch.float32, device=x.device)
-            ops.linear_wgrad(dqkv, x, a.qkv.weight, None, bias_out=dqb)
-            ops.grad_of(a.q_bias).add_(dqb[:C])
-            ops.grad_of(a.v_bias).add_(dqb[2 * C:])
+            st = ops.linear_wgrad(dqkv, x, a.qkv.weight, None, bias_out=dqb)
+            with torch.cuda.stream(st):                                 # the stream of the kernel that filled dqb
+                ops.grad_of(a.q_bias).add_(dqb[:C])
+                ops.grad_of(a.v_bias).add_(dqb[2 * C:])
         else:
             ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
         dx = ops.gemm_nt(dqkv, ops.weight_t(a.qkv.weight, ad), epi=hip.EPI_ADD_AUX, aux=g1)

@@ -37,8 +37,13 @@ def on_backward_done(tag, fn, key="default"):
 
 
 def fire_backward_done(tag):
-    for fn in list(_BACKWARD_DONE.get(tag, {}).values()):
+    cbs = list(_BACKWARD_DONE.get(tag, {}).values())
+    if (cbs or tag == "swin") and tag.startswith("swin"):
+        join_wgrad_stream()               # the image encoder's weight gradients run on their own stream: finish them first
+    for fn in cbs:
         fn()
+    if tag == "swin":
+        WGRAD_STREAM[0] = None            # the step's backward is over: later launches (other models, tests) stay on their own stream
 
 
 def bump_weight_epoch():
@@ -183,10 +188,33 @@ def wgrad_splitk(n_out, k_out, depth):
     return int(max(1, min(want, ktiles // 4 if ktiles >= 8 else 1)))
 
 
+# Weight-gradient stream: (main stream handle, side stream) set by the fused model for the duration of a step; weight gradients
+# issued from the main stream are moved to it (the other branches already run beside the main stream).
+WGRAD_STREAM = [None]
+
+
+def wgrad_stream_for_current():
+    ws = WGRAD_STREAM[0]
+    if ws is None or hip.TIMING.enabled:
+        return None
+    main, wg = ws
+    return wg if torch.cuda.current_stream().cuda_stream == main else None
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for every weight gradient issued so far (before anything reads them: all-reduce, optimizer)."""
+    ws = WGRAD_STREAM[0]
+    if ws is not None:
+        ev = torch.cuda.Event()
+        ev.record(ws[1])
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers.
-    bias_out: an fp32 [N] buffer to accumulate colsum(dy) into instead of b_param.grad (returns False if the path taken
-    could not fuse it, so the caller falls back to explicit column sums)."""
+    bias_out: an fp32 [N] buffer to accumulate colsum(dy) into instead of b_param.grad.  Returns the stream the gradient
+    kernels were issued on (the weight-gradient stream when one is active, else the current one): whoever consumes
+    bias_out must do so on that stream."""
     M, N = dy.shape
     K = x.shape[1]
     if (w_param is not None and dy.dtype == torch.float32 and x.dtype == torch.float32 and USE_SPLIT3[0] and USE_TN_WGRAD[0]
@@ -212,19 +240,34 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
         splitk = max(1, min(math.ceil(M / 64 / 4), splitk))
         hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
         bias_dst = bias_out if bias_out is not None else (grad_of(b_param) if b_param is not None else None)
-        call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(grad_of(w_param)), K, M, N, K,
-             ptr(bias_dst), splitk)
-        return True
+        gw = grad_of(w_param)
+        wg = wgrad_stream_for_current()
+        if wg is None:
+            call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk)
+        else:
+            # Nothing downstream in backward reads a weight gradient: it leaves the critical path and runs on the weight-gradient
+            # stream, ordered after the kernels that produced dy / x; the caching allocator is told both are still in use there.
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dy.device))
+            wg.wait_event(ev)
+            dy.record_stream(wg)
+            x.record_stream(wg)
+            if bias_out is not None:
+                bias_out.record_stream(wg)
+            with torch.cuda.stream(wg):
+                call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk)
+        return wg if wg is not None else torch.cuda.current_stream(dy.device)
     if bias_out is not None:
         colsum_into(dy, bias_out)
     if b_param is not None:
         colsum_into(dy, grad_of(b_param))
     if w_param is None:
-        return
+        return torch.cuda.current_stream(dy.device) if dy.is_cuda else None
     dyT = transpose(dy) if dyT is None else dyT
     xT = transpose(x) if xT is None else xT
     gw = grad_of(w_param)
     gemm_nt(dyT, xT, out=gw.view(N, K), out_mode=hip.OUT_ATOMIC, splitk=wgrad_splitk(N, K, M))
+    return torch.cuda.current_stream(dy.device) if dy.is_cuda else None
 
 
 _WS = {}

@@ -99,6 +99,9 @@ class ParamStore:
         all-reduce SUM."""
         if grad_scale is None:
             grad_scale = self.grad_scale
+        if self.flat.is_cuda:
+            ops.join_wgrad_stream()           # weight gradients issued on the side stream must have landed
+            ops.WGRAD_STREAM[0] = None
         self._sumsq.zero_()
         call("sumsq", ptr(self.grad), self.total, ptr(self._sumsq_partials), ptr(self._sumsq))
         call("clip_coef", ptr(self._sumsq), float(max_norm) if max_norm else 0.0, float(grad_scale), ptr(self.norm))
@@ -120,6 +123,9 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         st = self.store
+        if st.flat.is_cuda:
+            ops.join_wgrad_stream()
+            ops.WGRAD_STREAM[0] = None
         self._step += 1
         coef = st.norm if self._clipped else None
         for (a, b), grp in zip(st.group_ranges, self.param_groups):
