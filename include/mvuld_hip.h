@@ -115,7 +115,9 @@ int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, 
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                         float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes,
-                        int dtype, mvuld_stream_t stream);
+                        int passes, int dtype, mvuld_stream_t stream);
+/* passes: 1 = delta + dQ + dK/dV, 2 = bias-table gradient (mode 0; reads ws_delta / ws_qt written by pass 1), 3 = both.
+ * The bias-table gradient feeds nothing else in backward, so a caller may issue pass 2 later, on another stream. */
 
 /* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,

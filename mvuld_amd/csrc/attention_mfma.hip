@@ -947,9 +947,10 @@ extern "C" int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, i
 extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
-                                   float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int dtype,
-                                   hipStream_t stream) {
+                                   float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int passes,
+                                   int dtype, hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
+    MV_CHECK_ARG(passes >= 1 && passes <= 3, "attn_bwd_mfma: passes is a mask of 1 (delta + dQ + dK/dV) and 2 (bias-table gradient)");
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
     MV_CHECK_ARG(mode == 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
@@ -957,8 +958,9 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
     const int64_t ntok = (int64_t)B * nW * N;
-    hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H * (hd / 8), 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
-                       ws_delta, ntok, H, hd);
+    if (passes & 1)
+        hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H * (hd / 8), 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
+                           ws_delta, ntok, H, hd);
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);
     const size_t bytes_q = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
@@ -974,11 +976,13 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                            (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
                            Npad, split);                                                                                  \
     } while (0)
-    if (mode == 0 && hd == 32) { if (shift > 0) AM_BWD(32, 0, true); else AM_BWD(32, 0, false); }
-    else if (mode == 0) { if (shift > 0) AM_BWD(64, 0, true); else AM_BWD(64, 0, false); }
-    else if (hd == 32) AM_BWD(32, 1, false);
-    else AM_BWD(64, 1, false);
-    if (mode == 0) {
+    if (passes & 1) {
+        if (mode == 0 && hd == 32) { if (shift > 0) AM_BWD(32, 0, true); else AM_BWD(32, 0, false); }
+        else if (mode == 0) { if (shift > 0) AM_BWD(64, 0, true); else AM_BWD(64, 0, false); }
+        else if (hd == 32) AM_BWD(32, 1, false);
+        else AM_BWD(64, 1, false);
+    }
+    if (mode == 0 && (passes & 2)) {
         MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
         const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
         constexpr int DG = 4;                                   // dy per work item: ws = 28 -> 7 groups x 2 q parts = 14 items / 8 waves

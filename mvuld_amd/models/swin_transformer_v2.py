@@ -126,10 +126,14 @@ class _SwinBlockFn(torch.autograd.Function):
         dtable = torch.zeros((T2, H), dtype=torch.float32, device=x.device)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
                             ops.grad_of(a.logit_scale).view(-1))
-        cws = ops._workspace(x.device, hip.LIB.fn("mvuld_cpb_table_bwd_workspace_bytes")(T2, H))
-        call("cpb_table_bwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[2].weight), ptr(hidden), ptr(table16), ptr(dtable),
-             ptr(ops.grad_of(a.cpb_mlp[0].weight)), ptr(ops.grad_of(a.cpb_mlp[0].bias)), ptr(ops.grad_of(a.cpb_mlp[2].weight)), T2, H,
-             ptr(cws), cws.numel() * 4)
+        bst = ops.BIAS_STREAM[0]                  # where attn_bwd left dtable (the weight-gradient stream when one is active)
+        if bst is not None:
+            hidden.record_stream(bst)
+        with torch.cuda.stream(bst if bst is not None else torch.cuda.current_stream(x.device)):
+            cws = ops._workspace(x.device, hip.LIB.fn("mvuld_cpb_table_bwd_workspace_bytes")(T2, H))
+            call("cpb_table_bwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[2].weight), ptr(hidden), ptr(table16), ptr(dtable),
+                 ptr(ops.grad_of(a.cpb_mlp[0].weight)), ptr(ops.grad_of(a.cpb_mlp[0].bias)), ptr(ops.grad_of(a.cpb_mlp[2].weight)), T2, H,
+                 ptr(cws), cws.numel() * 4)
         if a.q_bias is not None:
             # q_bias / v_bias gradients = column sums of dqkv: taken from the weight-gradient kernel's fused column sum (one
             # [3C] scratch, two slice adds) instead of two more passes over dqkv

@@ -380,18 +380,35 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     return out, lse
 
 
+BIAS_STREAM = [None]       # stream on which the last attn_bwd left dtable16 (None = the current one)
+
+
 def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None):
     dqkv = torch.empty_like(qkv)
+    BIAS_STREAM[0] = None
     if _mfma_attn_ok(g, qkv.dtype):
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
         qt = torch.empty((qkv.shape[0], g.H * g.hd), dtype=torch.bfloat16, device=qkv.device) if g.mode == 0 else None
         hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
-        part = None
-        if g.mode == 0:
-            part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))     # one table per workgroup
-        call("attn_bwd_mfma", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
-             ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt), ptr(part), part.numel() * 4 if part is not None else 0,
-             dt(qkv))
+        args = (*g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
+                ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt))
+        wg = wgrad_stream_for_current() if g.mode == 0 else None
+        if g.mode != 0 or wg is None:
+            part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, dt(qkv))
+            return dqkv
+        # The bias-table gradient feeds nothing else in backward: dQ / dK / dV stay on this stream, the table pass (and whatever
+        # the caller does with dtable16 afterwards: see bias_stream) goes to the weight-gradient stream.
+        call("attn_bwd_mfma", *args, None, 0, 1, dt(qkv))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(qkv.device))
+        wg.wait_event(ev)
+        for t in (qkv, dout, lse, delta, qt, table16, logit_scale, dtable16, out):
+            t.record_stream(wg)
+        with torch.cuda.stream(wg):
+            part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, dt(qkv))
+        BIAS_STREAM[0] = wg
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
     call("attn_bwd_simple", *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
