@@ -116,11 +116,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const T* __restrict__ dy,
 // (CPL = ceil(C/8/G) <= 2 chunks per lane), 64/G rows per wave, statistics by xor-shuffles inside the lane group.
 // Every load is unconditional on a clamped address (a predicated load makes the compiler branch and drain vmcnt per load,
 // which serialises the x / pre / residual round trips); only the stores are predicated.
+// Sum over the G (power of two) consecutive lanes that share a row: DPP inside a 16-lane row, v_permlane16/32_swap across rows --
+// VALU only (a __shfl_xor butterfly is six dependent LDS-routed ds_bpermute per reduction).
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float group_sum(float v, int G) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_xor(v, o, 64);
-        v += (o < G) ? t : 0.f;
+    if (G >= 2) v += ln_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (G >= 4) v += ln_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (G >= 8) v += ln_dpp<0x141>(v);       // row_half_mirror: the other quad of the 8
+    if (G >= 16) v += ln_dpp<0x140>(v);      // row_mirror: the other half of the row
+    if (G >= 32) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    if (G >= 64) {
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
     }
     return v;
 }
