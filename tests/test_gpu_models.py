@@ -499,3 +499,40 @@ def test_fused_full_size_train_steps_reduce_loss(gpu):
         assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
     print("[full-size train] losses", [round(x, 4) for x in losses])
     assert losses[-1] < losses[0] - 0.03 and min(losses) == min(losses[3:])
+
+
+def test_fused_eval_forward_hipgraph_capture(gpu):
+    """BASELINE config 4's mechanism: the whole fused eval forward (full-size model, both streams, every launch through the C ABI)
+    captured once in a hipGraph and replayed must reproduce the eager logits bit for bit -- no host-side synchronisation,
+    allocation outside the graph pool or stream leak anywhere on the path."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16"], batch_size=4, local_rank=0))
+    model = build_fused_model(config)
+    load_synth_into(model)
+    model = model.to(gpu).eval()
+    f = config.FUSED
+    g, images, ids, _ = synthetic.make_batch([81, 82, 83, 84], config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g = g.to(gpu)
+    g.index()
+    images, ids = images.to(gpu), ids.to(gpu)
+    with torch.no_grad():
+        for _ in range(2):
+            eager = model(g, images, ids).float().clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(g, images, ids)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(g, images, ids)
+        for _ in range(3):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.float(), eager)
+
