@@ -86,7 +86,9 @@ int mvuld_batchnorm_fwd(const void* x, void* y, const float* gamma, const float*
                         int64_t sc, int64_t si, float eps, float momentum, int training, int dtype, mvuld_stream_t stream);
 int mvuld_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean,
                         const float* save_rstd, void* dx, float* dgamma, float* dbeta, int O, int C, int I,
-                        int64_t so, int64_t sc, int64_t si, int training, int dtype, mvuld_stream_t stream);
+                        int64_t so, int64_t sc, int64_t si, int training, float* dxsum, int dtype, mvuld_stream_t stream);
+/* dxsum (optional, [C] fp32, accumulated): per-channel sum of dx taken before dx is rounded to its storage type -- the bias
+ * gradient of a Linear / Conv1d(k=1) directly in front of the BatchNorm (Rs_GCN.py:27-34: W = Sequential(Conv1d, BatchNorm1d)). */
 
 /* Fused attention (reference-quality VALU kernels; f32 | bf16 storage).
  * mode 0: SwinV2 shifted-window cosine attention + continuous position bias + shift mask, with the roll /

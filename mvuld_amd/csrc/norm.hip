@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_k(const T* __restrict__ dy,
                                                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                        const float* __restrict__ save_rstd, T* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int O, int C,
-                                                       int I, int64_t so, int64_t sc, int64_t si, int training) {
+                                                       int I, int64_t so, int64_t sc, int64_t si, int training,
+                                                       float* __restrict__ dxsum) {
     __shared__ float red[16];
     const int c = blockIdx.x;
     const int64_t n = (int64_t)O * I;
@@ -484,10 +485,17 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_k(const T* __restrict__ dy,
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) { if (dgamma) atomicAdd(dgamma + c, s2); if (dbeta) atomicAdd(dbeta + c, s1); }
     const float m1 = training ? s1 / n : 0.f, m2 = training ? s2 / n : 0.f;
+    float sx = 0.f;
     for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
         const int64_t off = (e / I) * so + c * sc + (e % I) * si;
         const float xh = (ldf(x + off) - mu) * rs;
-        stf(dx + off, ga * rs * (ldf(dy + off) - m1 - xh * m2));
+        const float d = ga * rs * (ldf(dy + off) - m1 - xh * m2);
+        sx += d;
+        stf(dx + off, d);
+    }
+    if (dxsum) {                                   // per-channel sum of dx in fp32, before dx is rounded to its storage type: the
+        sx = block_sum(sx, red);                   // bias gradient of the layer in front (~0 under batch statistics: a sum of
+        if (threadIdx.x == 0) atomicAdd(dxsum + c, sx);      // cancelling terms that bf16 rounding would turn into noise)
     }
 }
 
@@ -509,15 +517,16 @@ extern "C" int mvuld_batchnorm_fwd(const void* x, void* y, const float* gamma, c
 
 extern "C" int mvuld_batchnorm_bwd(const void* dy, const void* x, const float* gamma, const float* save_mean,
                                    const float* save_rstd, void* dx, float* dgamma, float* dbeta, int O, int C, int I,
-                                   int64_t so, int64_t sc, int64_t si, int training, int dtype, hipStream_t stream) {
+                                   int64_t so, int64_t sc, int64_t si, int training, float* dxsum, int dtype,
+                                   hipStream_t stream) {
     MV_CHECK_ARG(O > 0 && C > 0 && I > 0, "batchnorm_bwd: empty");
     MV_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx, "batchnorm_bwd: null pointer");
     if (dtype == MVULD_F32)
         hipLaunchKernelGGL(batchnorm_bwd_k<float>, dim3(C), dim3(256), 0, stream, (const float*)dy, (const float*)x, gamma,
-                           save_mean, save_rstd, (float*)dx, dgamma, dbeta, O, C, I, so, sc, si, training);
+                           save_mean, save_rstd, (float*)dx, dgamma, dbeta, O, C, I, so, sc, si, training, dxsum);
     else
         hipLaunchKernelGGL(batchnorm_bwd_k<bf16>, dim3(C), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, gamma,
-                           save_mean, save_rstd, (bf16*)dx, dgamma, dbeta, O, C, I, so, sc, si, training);
+                           save_mean, save_rstd, (bf16*)dx, dgamma, dbeta, O, C, I, so, sc, si, training, dxsum);
     MV_LAUNCH_CHECK("batchnorm_bwd");
     return 0;
 }

@@ -54,8 +54,9 @@ class _RsGCNFn(torch.autograd.Function):
         ad = v.dtype
         conv, bn = mod.W[0], mod.W[1]
         dout = dout.contiguous()
-        dwy = ops.batchnorm_bwd(dout, wy, bn.weight, bn.bias, sm, sr, B * N, D, 1, D, 1, 1, training)
-        ops.linear_wgrad(dwy, y, conv.weight, conv.bias)
+        # the conv bias gradient (column sums of dwy, ~0 under batch statistics) comes from the BatchNorm kernel in fp32
+        dwy = ops.batchnorm_bwd(dout, wy, bn.weight, bn.bias, sm, sr, B * N, D, 1, D, 1, 1, training, dxsum=ops.grad_of(conv.bias))
+        ops.linear_wgrad(dwy, y, conv.weight, None)
         dy = ops.gemm_nt(dwy, ops.weight_t(conv.weight, ad))                                         # [B*N, Di]
         # y = R gv
         dR = ops.gemm_nt(dy, gv, M=N, N=N, K=Di, lda=Di, ldb=Di, batch=B, sa=N * Di, sb=N * Di)     # [B,N,N]

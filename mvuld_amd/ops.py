@@ -311,10 +311,11 @@ def batchnorm_fwd(x, gamma, beta, run_mean, run_var, O, C, I, so, sc, si, traini
     return y, sm, sr
 
 
-def batchnorm_bwd(dy, x, gamma_p, beta_p, sm, sr, O, C, I, so, sc, si, training):
+def batchnorm_bwd(dy, x, gamma_p, beta_p, sm, sr, O, C, I, so, sc, si, training, dxsum=None):
+    """dxsum: optional fp32 [C] buffer that receives += the per-channel sum of dx (before rounding to x.dtype)."""
     dx = torch.empty_like(x)
     call("batchnorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(sm), ptr(sr), ptr(dx), ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)),
-         O, C, I, so, sc, si, 1 if training else 0, dt(x))
+         O, C, I, so, sc, si, 1 if training else 0, ptr(dxsum), dt(x))
     return dx
 
 
