@@ -28,6 +28,7 @@ class FusedMVulD(nn.Module):
         self.head = Multi_DefectModel_new_GCN(config, act_dtype=act_dtype)
         self._side = None
         self._wg = None
+        self._inflight = []
         for n, p in self.head.named_parameters():
             if n.startswith(self.head.unused_parameter_prefixes):
                 p.requires_grad_(False)
@@ -54,6 +55,15 @@ class FusedMVulD(nn.Module):
             hfeat = self.head.forward_graph(g)
         else:
             main = torch.cuda.current_stream(images.device)
+            # Bound how far the host may run ahead of the GPU: tensors handed to another stream (record_stream) cannot be reused
+            # until that stream has passed them, so an unthrottled host (24 ms of enqueue per 66 ms step) keeps a few hundred MB
+            # more alive for every step it is ahead.  Two steps in flight lose nothing.
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._inflight.append(ev)
+                if len(self._inflight) > 2:
+                    self._inflight.pop(0).synchronize()
             if self._side is None:
                 self._side = torch.cuda.Stream(device=images.device)
             side = self._side
