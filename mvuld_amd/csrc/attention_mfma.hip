@@ -888,8 +888,13 @@ static int am_set_lds(F fn, size_t bytes, const char* name) {
 
 // enough workgroups to fill 256 CUs a few times over when (windows x heads) alone is small
 static int am_split(int64_t groups, int ntile) {
+    // Query / key tiles of one (window, head) are split over several workgroups only while there are fewer workgroups than
+    // ~2 per CU: every split re-stages the whole K/V (or Q~/dO) tile.  (1024 measured 14-25 % slower than 512 on the 512-group
+    // stage-2 layers and the 384-group text encoder.)
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("MVULD_ATTN_SPLIT_TARGET"); target = e ? atoi(e) : 512; }
     int s = 1;
-    while (groups * s < 1024 && s * 2 * 8 <= ntile) s *= 2;
+    while (groups * s < target && s * 2 * 8 <= ntile) s *= 2;
     return s;
 }
 
