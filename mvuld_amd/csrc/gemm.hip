@@ -1122,7 +1122,9 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
         // 3-15 % over the 128 x 128 ring on every shape of the step, -1.8 ms per step.  MVULD_GEMM_RING256X128 = minimum K (0 = off).
         static int ring4 = -1;
         if (ring4 < 0) { const char* e = getenv("MVULD_GEMM_RING256X128"); ring4 = e ? atoi(e) : 32; }
-        if (ring4 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= ring4 && (int64_t)cdiv(M, G4_BM) * tiles_n * batch >= 256) {
+        static int ring4_tiles = -1;
+        if (ring4_tiles < 0) { const char* e = getenv("MVULD_GEMM_RING256X128_TILES"); ring4_tiles = e ? atoi(e) : 256; }
+        if (ring4 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= ring4 && (int64_t)cdiv(M, G4_BM) * tiles_n * batch >= ring4_tiles) {
             const int tm4 = (int)cdiv(M, G4_BM);
             static bool attr4 = false;
             if (!attr4) {
