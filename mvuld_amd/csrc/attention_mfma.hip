@@ -343,7 +343,7 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
 }
 
 template <int HD, int MODE, bool MASK>
-__global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+__global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                           const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -737,7 +737,7 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
 }
 
 template <int HD, int MODE, bool MASK>
-__global__ __launch_bounds__(HD == 32 ? 1024 : 512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+__global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd_dkv_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                            const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv, int Npad, int ksplit) {
@@ -901,7 +901,7 @@ static int am_split(int64_t groups, int ntile) {
 #define AM_LAUNCH(KERNEL, HDV, MODEV, bytes, ...)                                                \
     do {                                                                                          \
         if (am_set_lds(KERNEL<HDV, MODEV>, bytes, #KERNEL)) return 1;                             \
-        hipLaunchKernelGGL((KERNEL<HDV, MODEV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes, stream, __VA_ARGS__);    \
+        hipLaunchKernelGGL((KERNEL<HDV, MODEV>), grid, dim3((HDV == 32 || MODEV == 1) ? 1024 : 512), bytes, stream, __VA_ARGS__);    \
     } while (0)
 
 #define AM_DISPATCH(KERNEL, bytes, ...)                                      \
@@ -973,11 +973,11 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
 #define AM_BWD(HDV, MODEV, MASKV)                                                                                       \
     do {                                                                                                                 \
         if (am_set_lds(attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>, bytes_q, "attn_bwd_dq_mfma_k")) return 1;                  \
-        hipLaunchKernelGGL((attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes_q, stream, g, \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>), grid, dim3((HDV == 32 || MODEV == 1) ? 1024 : 512), bytes_q, stream, g, \
                            (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
                            dlogit_scale, (bf16*)ws_qt, Npad, split);                                                                  \
         if (am_set_lds(attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>, bytes_k, "attn_bwd_dkv_mfma_k")) return 1;                 \
-        hipLaunchKernelGGL((attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>), grid, dim3(HDV == 32 ? 1024 : 512), bytes_k, stream, g, \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>), grid, dim3((HDV == 32 || MODEV == 1) ? 1024 : 512), bytes_k, stream, g, \
                            (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
                            Npad, split);                                                                                  \
     } while (0)
