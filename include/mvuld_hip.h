@@ -48,11 +48,23 @@ int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, in
  * (K % 32 == 0, >= 128 tiles, plain store) take it; 0 (default) = never.  No stream argument: host-side setting. */
 int mvuld_set_gemm_256_min_k(int min_k);
 
+/* Routing of mvuld_gemm_nt's bf16 -> bf16 plain-store products to the persistent 256 x 256-tile kernel (csrc/gemm_p256.hip):
+ * 0 = never, 1 = default rule (>= 160 tiles, N % 128 == 0: the tall Linear layers of the two encoders, same call sites as
+ * mvuld_gemm_nt), 2 = every legal shape (K % 32 == 0, K >= 128, N % 8 == 0, no ELU epilogues; tests and A/B timing).  Host-side setting, no stream. */
+int mvuld_set_gemm_p256_mode(int mode);
+/* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
+ * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */
+int mvuld_set_gemm_p256_rows(int rows);
+
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
- * layout, fp32 atomic accumulate, contraction split over `splitk` workgroups); dbias[N] += column sums of dY when non-null.
+ * layout, contraction split over `splitk` workgroups per 128 x 128 output tile); dbias[N] += column sums of dY when non-null.
+ * `ws` (optional, caller-owned, ws_bytes >= mvuld_gemm_tn_wgrad_workspace_bytes(N, K, splitk), 16-byte aligned, ZEROED ONCE by
+ * the caller when allocated, then private to one stream): the splits exchange fp32 partial tiles through it and only the
+ * last one to finish adds into dW; without it every split adds its partial into dW with fp32 atomics (splitk x the traffic).
  * The autograd of every nn.Linear weight/bias on the path (same call sites as mvuld_gemm_nt). */
+int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int N, int K, int splitk);   /* 0 = this shape cannot use a workspace */
 int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
-                        float* dbias, int splitk, mvuld_stream_t stream);
+                        float* dbias, int splitk, void* ws, int64_t ws_bytes, mvuld_stream_t stream);
 
 /* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
 int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);

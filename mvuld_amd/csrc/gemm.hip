@@ -14,17 +14,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6 };
-enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_ATOMIC = 2 };
-
-struct GemmArgs {
-    const void* A; const void* B; void* C;
-    int64_t lda, ldb, ldc, sA, sB, sC;     // leading dims and batch strides, in elements
-    int M, N, K, batch, splitk;
-    const float* bias;                     // [N] or null
-    void* aux; int64_t ldaux, sAux;        // pre-activation (GELU out / dGELU in) or ELU output (dELU in); dtype of C
-    float alpha; int epi; int out_mode;
-};
+#include "gemm_common.h"
 
 template <typename TO>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, TO* C, TO* aux, int row, int col, float acc) {
@@ -103,10 +93,6 @@ __global__ __launch_bounds__(256) void gemm_nt_simple(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------ MFMA bf16
-typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
-typedef float __attribute__((ext_vector_type(4))) f32x4_t;
-typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
-
 #define GT_BM 128
 #define GT_BN 128
 #define GT_BK 64
@@ -321,9 +307,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
                 float x = g.alpha * v[e] + bias8[e];
                 pre[e] = x;
                 switch (g.epi) {
-                    case EPI_GELU: x = gelu_erf(x); break;
+                    case EPI_GELU: x = gelu_t<TO>(x); break;
                     case EPI_ELU: x = elu1(x); break;
-                    case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                    case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                     case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
                     case EPI_ADD_AUX: x += ax[e]; break;
                     default: break;
@@ -515,9 +501,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int 
                     float x = g.alpha * v[e] + bias8[e];
                     pre[e] = x;
                     switch (g.epi) {
-                        case EPI_GELU: x = gelu_erf(x); break;
+                        case EPI_GELU: x = gelu_t<TO>(x); break;
                         case EPI_ELU: x = elu1(x); break;
-                        case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                        case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
                         case EPI_ADD_AUX: x += ax[e]; break;
                         default: break;
@@ -696,9 +682,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
                     float x = g.alpha * v[e] + bias8[e];
                     pre[e] = x;
                     switch (g.epi) {
-                        case EPI_GELU: x = gelu_erf(x); break;
+                        case EPI_GELU: x = gelu_t<TO>(x); break;
                         case EPI_ELU: x = elu1(x); break;
-                        case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                        case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
                         case EPI_ADD_AUX: x += ax[e]; break;
                         default: break;
@@ -877,9 +863,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
                     float x = g.alpha * v[e] + bias8[e];
                     pre[e] = x;
                     switch (g.epi) {
-                        case EPI_GELU: x = gelu_erf(x); break;
+                        case EPI_GELU: x = gelu_t<TO>(x); break;
                         case EPI_ELU: x = elu1(x); break;
-                        case EPI_MUL_DGELU: x *= dgelu_erf(ax[e]); break;
+                        case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
                         case EPI_ADD_AUX: x += ax[e]; break;
                         default: break;
@@ -939,7 +925,8 @@ __device__ __forceinline__ bf16x8_t tn_read_tr(const bf16* tile, int m0, int col
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ B, int64_t ldb,
                                                             float* __restrict__ C, int64_t ldc, int M, int N, int K, int splitk,
-                                                            float* __restrict__ colsum, int tiles_n, int tiles_k) {
+                                                            float* __restrict__ colsum, int tiles_n, int tiles_k,
+                                                            float* __restrict__ slabs, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1032,6 +1019,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
         cur ^= 1;
     }
     if (colsum && tk == 0 && tid < 128 && n0 + tid < N) atomicAdd(colsum + n0 + tid, csum);
+    // ---- combine the split contraction.  With a workspace: every split writes its 128 x 128 fp32 partial as a 64 KiB slab in
+    // REGISTER order (one float4 per (fragment, lane): 1 KiB per store instruction, write-through `sc1` stores, so no release
+    // fence), draws a ticket, and the split that draws the last one adds the other slabs to its registers and is the only one
+    // to touch dW.  fp32 atomics from every split instead (no workspace) move splitk x the bytes at a fifth of the store rate:
+    // 35 MB / launch on this model's shapes, about a third of the kernel's time.
+    const int nsplit = (mtiles + per - 1) / per;             // splits with a non-empty slab range (the others returned above)
+    if (slabs && nsplit > 1) {
+        float* mine = slabs + ((size_t)tl * nsplit + ks) * (128 * 128);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 128 * 128 * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rsrc, ((wave * 16 + i * 4 + j) * 64 + lane) * 16, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+        __syncthreads();                                      // ... before the one ticket that publishes them all
+        unsigned* flag = (unsigned*)smem;                     // the staging tiles are dead: every wave passed the loop's last barrier
+        if (tid == 0) *flag = __hip_atomic_fetch_add(tickets + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)(nsplit - 1)) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(tickets + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+        }
+        __syncthreads();
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            if (sidx == ks) continue;
+            const float* other = slabs + ((size_t)tl * nsplit + sidx) * (128 * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += *(const f32x4_t*)(other + ((wave * 16 + i * 4 + j) * 64 + lane) * 4);
+        }
+    }
     // epilogue: acc[i][j][r] = C[n = n0 + wr*64 + i*16 + 4*fg + r][k = k0 + wc*64 + j*16 + fr]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1045,8 +1067,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
 }
 
 // dW[N,K] += dY[M,N]^T . X[M,K]  (fp32 atomic accumulate);  optional db[N] += column sums of dY
+// workspace of mvuld_gemm_tn_wgrad for an N x K weight: one 4-byte ticket per 128 x 128 output tile (kept at 0 between
+// launches by the kernel itself: the caller zeroes the buffer ONCE, when it allocates it) followed by splitk 64 KiB slabs per tile
+#define TN_TICKET_BYTES 4096
+extern "C" int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int N, int K, int splitk) {
+    const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
+    if (splitk < 2 || tiles * 4 > TN_TICKET_BYTES) return 0;
+    return TN_TICKET_BYTES + tiles * splitk * (int64_t)(128 * 128 * 4);
+}
+
 extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
-                                   float* dbias, int splitk, hipStream_t stream) {
+                                   float* dbias, int splitk, void* ws, int64_t ws_bytes, hipStream_t stream) {
     MV_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0, "gemm_tn_wgrad: bad args");
     MV_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)dY | (uintptr_t)X) & 15) == 0,
                  "gemm_tn_wgrad: operands must be 16-byte aligned with N, K multiples of 8");
@@ -1054,12 +1085,24 @@ extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, i
     const int mtiles = (int)cdiv(M, TN_BM);
     if (splitk < 1) splitk = 1;
     if (splitk > mtiles) splitk = mtiles;
-    static bool attr = false;
+    float* slabs = nullptr;
+    unsigned* tickets = nullptr;
+    if (ws && splitk > 1) {
+        const int64_t need = mvuld_gemm_tn_wgrad_workspace_bytes(N, K, splitk);
+        MV_CHECK_ARG(need > 0 && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0, "gemm_tn_wgrad: workspace too small (%lld < %lld bytes) or misaligned",
+                     (long long)ws_bytes, (long long)need);
+        tickets = (unsigned*)ws;
+        slabs = (float*)((char*)ws + TN_TICKET_BYTES);
+    }
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN_TILE_BYTES);
+        return true;
+    }();
+    (void)attr;
     const int lds = 4 * TN_TILE_BYTES;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_mfma_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
     dim3 grid(tiles_n * tiles_k * splitk);
     hipLaunchKernelGGL(gemm_tn_mfma_bf16, grid, dim3(256), lds, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, dW, ldw, M, N, K, splitk,
-                       dbias, tiles_n, tiles_k);
+                       dbias, tiles_n, tiles_k, slabs, tickets);
     MV_LAUNCH_CHECK("gemm_tn_wgrad");
     return 0;
 }
@@ -1095,6 +1138,8 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
                          (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const bool use_mfma = (dtype_in == MVULD_BF16) && aligned && !force_simple && (M >= 32) && (N >= 32);
     if (use_mfma) {
+        // persistent 256 x 256 kernel (gemm_p256.hip): the tall bf16 -> bf16 products of the two encoders
+        if (mvuld_gemm_nt_p256_try(g, dtype_out, stream) == 0) { MV_LAUNCH_CHECK("gemm_nt_bf16_p256"); return 0; }
         // 256 x 256 LDS-DMA ring kernel: opt-in (mvuld_set_gemm_256_min_k / MVULD_GEMM_256 = minimum K, 0 = off, the default:
         // in the full step it is a wash -- faster alone from K >= 1536, slower cold and on partial last rounds at 1 workgroup / CU)
         if (g_k256 < 0) { const char* e = getenv("MVULD_GEMM_256"); g_k256 = e ? atoi(e) : 0; }

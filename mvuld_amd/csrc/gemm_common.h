@@ -1,0 +1,48 @@
+// Shared by the GEMM translation units of libmvuld_hip.so (gemm.hip, gemm_p256.hip).
+#pragma once
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6 };
+enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_ATOMIC = 2 };
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    int64_t lda, ldb, ldc, sA, sB, sC;     // leading dims and batch strides, in elements
+    int M, N, K, batch, splitk;
+    const float* bias;                     // [N] or null
+    void* aux; int64_t ldaux, sAux;        // pre-activation (GELU out / dGELU in) or ELU output (dELU in); dtype of C
+    float alpha; int epi; int out_mode;
+};
+
+typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
+typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
+
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): 1 v_rcp + 1 v_exp + ~10 plain VALU, against ~40 for ocml's erff.
+// Used where the result is rounded to bf16 anyway (bf16-output GEMM epilogues); the fp32 parity mode keeps erff.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_fast(float x) {
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
+template <typename TO> __device__ __forceinline__ float gelu_t(float x) {
+    if constexpr (sizeof(TO) == 2) return gelu_fast(x); else return gelu_erf(x);
+}
+template <typename TO> __device__ __forceinline__ float dgelu_t(float x) {
+    if constexpr (sizeof(TO) == 2) return dgelu_fast(x); else return dgelu_erf(x);
+}
+
+// persistent 256 x 256 NT kernel (gemm_p256.hip); returns 0 when it took the launch, -1 when the shape is not its to take
+int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream);

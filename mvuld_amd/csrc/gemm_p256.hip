@@ -1,0 +1,341 @@
+// Persistent 256 x 256-tile NT GEMM for the step's tall products (M = tokens >> N):  C = epi(alpha * A . B^T + bias), bf16 in / bf16 out.
+//
+// Why another kernel: the 256 x 128 ring of gemm.hip moves 85 FLOP per byte it pulls from L2 and tops out near the L2 -> LDS
+// bandwidth (~12 TB/s observed = 1.0 PFLOP/s at 4096^3); a 256 x 256 tile is 128 FLOP per byte.  At one 8-wave workgroup per CU
+// (128 KiB of LDS) the launch-per-tile form of that tile lost on this model's short contractions (K = 512 .. 768: 16-24 k-steps),
+// because nothing overlapped a tile's prologue (first loads) and epilogue.  This version is persistent:
+//   * grid = min(tiles, CUs); a workgroup walks tiles  b, b + G, b + 2G, ...  of an XCD-contiguous order (blocks b, b+8, ... share
+//     an XCD, each XCD owns a contiguous run of tiles walked N-fastest, so an A row panel is pulled from HBM by one L2);
+//   * ONE ring of four 32-deep LDS stages (A 256 x 32 + B 256 x 32 bf16 = 32 KiB each) filled by LDS-DMA
+//     (global_load_lds_dwordx4, source-side XOR swizzle, no VGPR staging, no ds_write) runs ACROSS tiles: three k-steps are always in
+//     flight behind counted `s_waitcnt vmcnt`, so the next tile's first stages land while this tile's epilogue runs;
+//   * the epilogue uses no LDS (the ring is busy): the MFMA operands are swapped -- weights feed the A port, activations the B
+//     port -- so each lane's four accumulator registers are four CONSECUTIVE output columns of one row; two v_permlane16_swap per
+//     fragment pair turn them into 16-byte row segments (16 rows x 64 contiguous bytes per store instruction).  aux operands
+//     (dGELU pre-activation, residual-gradient join) are fetched as the same 16-byte segments and un-swapped;
+//   * GELU / dGELU use the 13-instruction erf of gemm_common.h (outputs are rounded to bf16 anyway).
+// M and N tails: DMA rows are clamped, stores predicated (N % 8 == 0).  K % 32 == 0.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+#define P_BN 256
+#define P_BK 32
+#define P_STAGE_BYTES 32768
+#define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
+#define P_LDS_BYTES (4 * P_STAGE_BYTES + 2048)
+
+// byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [256][32] bf16 tile (64-byte rows): slot XORed with the row group so
+// that every 16-lane group of a ds_read_b128 fragment read covers all 64 banks (same image as gemm.hip's ring kernels)
+__device__ __forceinline__ int p_off(int row, int ch) { return row * 64 + ((ch ^ ((4 - ((row >> 2) & 3)) & 3)) << 4); }
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+    bf16x2_t v = {(bf16)a, (bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NI = 16-row accumulator fragments per wave along M: the tile is (32 * NI) x 256, NI = 8 -> 256 x 256.  The host picks NI per
+// launch so that the tiles fill whole rounds of the persistent grid (a 25088 x 2048 product is 784 tiles of 256 rows = 3.06 rounds of
+// 256 workgroups, but 1256 tiles of 160 rows = 4.9 rounds of 0.67 the length).
+template <int EPI, int NI>
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    constexpr int BM = 32 * NI, WM = 16 * NI;           // tile rows, rows per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;            // 2 x 4 waves, WM (m) x 64 (n) each
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nt = tiles_m * tiles_n;
+    const int G = gridDim.x, bx = blockIdx.x;
+    const int nk = g.K / P_BK;
+    const int my_tiles = bx < nt ? (nt - bx + G - 1) / G : 0;
+    const int total = my_tiles * nk;
+    const bf16* A = (const bf16*)g.A;
+    const bf16* B = (const bf16*)g.B;
+    bf16* C = (bf16*)g.C;
+    bf16* aux = (bf16*)g.aux;
+
+    auto tile_of = [&](int ord, int& m0, int& n0) {      // ord-th tile of this workgroup
+        const int p = bx + ord * G;
+        const int q = nt >> 3, r = nt & 7, x = p & 7, i = p >> 3;
+        const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        m0 = (t / tiles_n) * BM;
+        n0 = (t % tiles_n) * P_BN;
+    };
+
+    // ---- DMA issue stream (runs three k-steps ahead of the compute stream, across tile boundaries)
+    // one instruction fills 1 KiB = 16 tile rows in lane order (lane l -> row l >> 2, slot l & 3): the lane fetches the chunk the
+    // swizzle keeps in its slot.  The A tile is 2 * NI pieces: wave w issues piece w and, if it exists, piece w + 8; the B tile is
+    // 16 pieces: wave w issues pieces 2w, 2w + 1.  So a wave has 3 or 4 operations per k-step in flight (the counted waits below).
+    const bool a2 = wave + 8 < 2 * NI;                   // wave-uniform
+    const bf16* ga[2];
+    const bf16* gb[2];
+    int iss_ord = 0, iss_kt = 0, issued = 0;
+    auto setup_ptrs = [&](int ord) {
+        int m0, n0;
+        tile_of(ord, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rowa = (wave + 8 * i) * 16 + (lane >> 2);
+            const int rowb = (wave * 2 + i) * 16 + (lane >> 2);
+            ga[i] = A + (int64_t)min(m0 + rowa, g.M - 1) * g.lda + ((lane & 3) ^ ((4 - ((rowa >> 2) & 3)) & 3)) * 8;
+            gb[i] = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb + ((lane & 3) ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 8;
+        }
+        // the tile's 256 bias columns ride the same DMA queue (a VGPR load in the epilogue would make hipcc drain it with
+        // vmcnt(0)); older than the tile's first operand stage, so the wait that retires that stage retires it too
+        if (g.bias && wave == 0) {
+            const int c = n0 + 4 * lane;
+            __builtin_amdgcn_global_load_lds((glb_vp)(g.bias + (c < g.N ? c : 0)), (lds_vp)(smem + P_BIAS_OFF + (ord & 1) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_one = [&]() {
+        if (issued < total) {
+            char* st = smem + (issued & 3) * P_STAGE_BYTES;
+            const int k0 = iss_kt * P_BK;
+            __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + wave * 1024), 16, 0, 0);
+            if (a2) __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave + 8) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + 16384 + (wave * 2) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gb[1] + k0), (lds_vp)(st + 16384 + (wave * 2 + 1) * 1024), 16, 0, 0);
+            ++issued;
+            if (++iss_kt == nk) {
+                iss_kt = 0;
+                if (++iss_ord < my_tiles) setup_ptrs(iss_ord);
+            }
+        }
+    };
+    if (my_tiles > 0) setup_ptrs(0);
+    issue_one();
+    issue_one();
+    issue_one();
+
+    // fragment byte offsets inside a stage: weights (MFMA A port) 4 x 16 columns, activations (B port) NI x 16 rows
+    int oa[NI], ob[4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) oa[i] = p_off(wr * WM + i * 16 + fr, fg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = 16384 + p_off(wc * 64 + j * 16 + fr, fg);
+
+    // stores one epilogue leaves in flight (known exactly only for a wave whose sub-tile is interior: every store executes)
+    constexpr int ST1 = 2 * NI, ST2 = 4 * NI;
+    int pend = 0;
+    int cs = 0;                                          // compute step, counted across tiles (ring stage = cs & 3)
+    for (int ord = 0; ord < my_tiles; ++ord) {
+        f32x4_t acc[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt, ++cs) {
+            // Step cs has landed once at most the operations issued after it are still in flight: normally the two younger k-steps
+            // (3 or 4 loads each); in the first three steps after an epilogue also that epilogue's stores, which were issued between
+            // step cs's loads and now -- counting them lets the stores drain under the MFMAs instead of in front of them.  vmcnt
+            // retires in issue order, so from the fourth step on the stores are older than the awaited loads and must be complete.
+            const int younger = total - 1 - cs;
+            if (younger >= 2) {
+                if (kt < 3 && pend == ST1) { if (a2) wait_vm<8 + ST1>(); else wait_vm<6 + ST1>(); }
+                else if (kt < 3 && pend == ST2) { if (a2) wait_vm<8 + ST2>(); else wait_vm<6 + ST2>(); }
+                else if (a2) wait_vm<8>();
+                else wait_vm<6>();
+            } else if (younger == 1) {
+                if (a2) wait_vm<4>(); else wait_vm<3>();
+            } else {
+                wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done with step cs - 1
+            issue_one();                                 // step cs + 3 refills the stage step cs - 1 occupied
+            const char* st = smem + (cs & 3) * P_STAGE_BYTES;
+            bf16x8_t fa[NI], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + ob[j]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+
+        // ---- epilogue, straight from the accumulators:  acc[i][j][r] = C[m0 + wr*WM + i*16 + fr][n0 + wc*64 + j*16 + 4*fg + r]
+        int m0, n0;
+        tile_of(ord, m0, n0);
+        const int nw = n0 + wc * 64, mw = m0 + wr * WM;
+        float b4[4][4];
+        if (g.bias) {
+            // inline asm: a ds_read hipcc can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0) in front of every read)
+            const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + P_BIAS_OFF + (ord & 1) * 1024 + (wc * 64 + 4 * fg) * 4);
+            f32x4_t t0, t1, t2, t3;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                         "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ba) : "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { b4[0][r] = t0[r]; b4[1][r] = t1[r]; b4[2][r] = t2[r]; b4[3][r] = t3[r]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j][0] = b4[j][1] = b4[j][2] = b4[j][3] = 0.f;
+        }
+        // aux operands (dGELU pre-activation / residual-gradient join) as the same 16-byte row segments the stores use, fetched one
+        // fragment row ahead of their use: a load issued right before its use would wait for every store in front of it
+        constexpr bool AUX_IN = EPI >= EPI_MUL_DGELU;
+        uint4 z[NI][2];
+        auto load_aux = [&](int i) {
+            const int row = mw + i * 16 + fr;
+            const int rowc = row < g.M ? row : g.M - 1;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int col = nw + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
+                z[i][jp] = *(const uint4*)(aux + (int64_t)rowc * g.ldaux + (col < g.N ? col : 0));
+            }
+        };
+        if (AUX_IN) { load_aux(0); load_aux(1); }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (AUX_IN && i + 2 < NI) load_aux(i + 2);
+            const int row = mw + i * 16 + fr;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int j0 = 2 * jp;
+                // after the swaps this lane owns columns  nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8 .. + 7  of `row`
+                const int col = nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8;
+                const bool ok = row < g.M && col < g.N;
+                float x[2][4];
+                if (AUX_IN) {
+                    const uint4 zz = z[i][jp];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(zz.x, zz.z, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(zz.y, zz.w, false, false);
+                    x[0][0] = bf_lo(s0[0]); x[0][1] = bf_hi(s0[0]); x[0][2] = bf_lo(s1[0]); x[0][3] = bf_hi(s1[0]);
+                    x[1][0] = bf_lo(s0[1]); x[1][1] = bf_hi(s0[1]); x[1][2] = bf_lo(s1[1]); x[1][3] = bf_hi(s1[1]);
+                }
+                float v[2][4], pre[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = g.alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
+                        pre[h][r] = t;
+                        if (EPI == EPI_GELU) t = gelu_fast(t);
+                        else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
+                        else if (EPI == EPI_ADD_AUX) t += x[h][r];
+                        v[h][r] = t;
+                    }
+                {
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][0], v[0][1]), pk_bf16(v[1][0], v[1][1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][2], v[0][3]), pk_bf16(v[1][2], v[1][3]), false, false);
+                    if (ok) *(uint4*)(C + (int64_t)row * g.ldc + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+                if (EPI == EPI_GELU && aux) {
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][2], pre[0][3]), pk_bf16(pre[1][2], pre[1][3]), false, false);
+                    if (ok) *(uint4*)(aux + (int64_t)row * g.ldaux + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+        const bool interior = (mw + WM <= g.M) && (nw + 64 <= g.N);      // wave-uniform: every store above was issued
+        pend = interior ? ((EPI == EPI_GELU && aux) ? ST2 : ST1) : 0;
+    }
+}
+
+static int p256_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
+template <int EPI, int NI>
+static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const int tiles_m = (int)cdiv(g.M, 32 * NI);
+    const int nt = tiles_m * tiles_n;
+    const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+}
+
+template <int EPI>
+static void p256_launch_ni(const GemmArgs& g, int ni, int tiles_n, hipStream_t stream) {
+    switch (ni) {
+        case 4: p256_launch<EPI, 4>(g, tiles_n, stream); break;
+        case 5: p256_launch<EPI, 5>(g, tiles_n, stream); break;
+        case 6: p256_launch<EPI, 6>(g, tiles_n, stream); break;
+        case 7: p256_launch<EPI, 7>(g, tiles_n, stream); break;
+        default: p256_launch<EPI, 8>(g, tiles_n, stream); break;
+    }
+}
+
+// Routing of mvuld_gemm_nt to this kernel: 0 = never, 1 = default rule, 2 = whenever the shape is legal.  Initialised from
+// MVULD_GEMM_P256 (A/B runs of tools/gemm_shapes.py); mvuld_set_gemm_p256_mode() overrides it (tests).
+#include <atomic>
+static std::atomic<int> g_p256_mode{-1};
+static int p256_mode() {
+    int m = g_p256_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("MVULD_GEMM_P256");
+        m = e ? atoi(e) : 1;
+        if (m < 0 || m > 2) m = 1;
+        g_p256_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" int mvuld_set_gemm_p256_mode(int mode) {
+    MV_CHECK_ARG(mode >= 0 && mode <= 2, "set_gemm_p256_mode: mode must be 0, 1 or 2");
+    g_p256_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+static std::atomic<int> g_p256_ni{0};      // 0 = pick per shape; 4..8 = force (A/B timing)
+extern "C" int mvuld_set_gemm_p256_rows(int rows) {
+    MV_CHECK_ARG(rows == 0 || (rows % 32 == 0 && rows >= 128 && rows <= 256), "set_gemm_p256_rows: 0 (auto) or 128, 160, 192, 224, 256");
+    g_p256_ni.store(rows / 32, std::memory_order_relaxed);
+    return 0;
+}
+
+// Tile height for an M x N product on a persistent grid of `cus` workgroups: the NI in 4..8 (rows = 32 * NI) that minimises
+// rounds(NI) x cost(NI), cost = a fixed share per tile (weights stage, prologue / epilogue latencies) + a share per 16-row fragment.
+static int p256_pick_ni(int M, int tiles_n, int cus) {
+    int best = 8;
+    double best_t = 1e30;
+    for (int ni = 8; ni >= 4; --ni) {
+        const int64_t nt = cdiv(M, 32 * ni) * tiles_n;
+        const double rounds = (double)cdiv(nt, cus);
+        const double t = rounds * (0.28 + 0.09 * ni);
+        if (t < best_t * 0.97) { best_t = t; best = ni; }      // prefer the taller tile unless the shorter one wins by > 3 %
+    }
+    return best;
+}
+
+int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream) {
+    const int mode = p256_mode();
+    if (mode == 0 || dtype_out != MVULD_BF16 || g.batch != 1 || g.splitk != 1 || g.out_mode != OUT_STORE) return -1;
+    if (g.K % P_BK != 0 || g.K < 4 * P_BK || g.N % 8 != 0 || g.ldc % 8 != 0 || (((uintptr_t)g.C) & 15) != 0) return -1;
+    if (g.aux && (g.ldaux % 8 != 0 || (((uintptr_t)g.aux) & 15) != 0)) return -1;
+    if (g.bias && (((uintptr_t)g.bias) & 15) != 0) return -1;
+    if (g.epi == EPI_ELU || g.epi == EPI_MUL_DELU) return -1;      // head-only epilogues: small products, not this kernel's
+    const int tiles_n = (int)cdiv(g.N, P_BN);
+    if (mode == 1) {
+        // default rule: enough whole tiles to occupy most of the chip, and little of the last column tile wasted
+        if (cdiv(g.M, 256) * tiles_n < 160 || g.N % 128 != 0) return -1;
+        if ((int64_t)tiles_n * P_BN > (int64_t)g.N * 5 / 4) return -1;
+    }
+    int ni = g_p256_ni.load(std::memory_order_relaxed);
+    if (ni == 0) ni = p256_pick_ni(g.M, tiles_n, p256_num_cus());
+    switch (g.epi) {
+        case EPI_NONE: case EPI_BIAS: p256_launch_ni<EPI_BIAS>(g, ni, tiles_n, stream); break;
+        case EPI_GELU: p256_launch_ni<EPI_GELU>(g, ni, tiles_n, stream); break;
+        case EPI_MUL_DGELU: p256_launch_ni<EPI_MUL_DGELU>(g, ni, tiles_n, stream); break;
+        case EPI_ADD_AUX: p256_launch_ni<EPI_ADD_AUX>(g, ni, tiles_n, stream); break;
+        default: return -1;
+    }
+    return 0;
+}

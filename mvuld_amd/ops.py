@@ -19,6 +19,7 @@ FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU 
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
 USE_SPLIT3 = [False]                 # fp32 GEMMs (the head's fp32 tail) as 3-term bf16 splits on the matrix cores
 USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
+USE_TN_SLABS = [os.environ.get("MVULD_TN_SLABS", "1") != "0"]     # ... whose split contraction (2..8 ways) goes through a slab workspace, not atomics
 
 
 # callbacks fired when the LAST backward of an encoder has run, i.e. all its gradients are final (used to start
@@ -210,6 +211,29 @@ def join_wgrad_stream():
         torch.cuda.current_stream().wait_event(ev)
 
 
+_TN_WS = {}
+
+
+def _tn_workspace(device, nbytes):
+    """Zero-initialised split-K exchange buffer of the weight-gradient kernel, one per (device, stream): its ticket words must be
+    0 before a launch and the kernel leaves them 0, so it is cleared once, here, and then only ever reused in stream order."""
+    if nbytes <= 0:
+        return None
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _TN_WS[key] = torch.zeros(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk):
+    # measured (tools/gemm_shapes.py): the last-arriver reduction wins 3-5 % up to ~8 splits (the wide weights of stage 2/3 and of the
+    # text encoder) and loses beyond (its serial slab reads grow with the split count: small weights x 400 k tokens)
+    ws = _tn_workspace(dy.device, hip.LIB.fn("mvuld_gemm_tn_wgrad_workspace_bytes")(N, K, splitk)) if (USE_TN_SLABS[0] and 2 <= splitk <= 8) else None
+    call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk,
+         ptr(ws), ws.numel() if ws is not None else 0)
+
+
 def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers.
     bias_out: an fp32 [N] buffer to accumulate colsum(dy) into instead of b_param.grad.  Returns the stream the gradient
@@ -243,7 +267,7 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
         gw = grad_of(w_param)
         wg = wgrad_stream_for_current()
         if wg is None:
-            call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk)
+            _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk)
         else:
             # Nothing downstream in backward reads a weight gradient: it leaves the critical path and runs on the weight-gradient
             # stream, ordered after the kernels that produced dy / x; the caching allocator is told both are still in use there.
@@ -255,7 +279,7 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
             if bias_out is not None:
                 bias_out.record_stream(wg)
             with torch.cuda.stream(wg):
-                call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk)
+                _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk)
         return wg if wg is not None else torch.cuda.current_stream(dy.device)
     if bias_out is not None:
         colsum_into(dy, bias_out)

@@ -536,3 +536,53 @@ def test_fused_eval_forward_hipgraph_capture(gpu):
             torch.cuda.synchronize()
             assert torch.equal(out.float(), eager)
 
+
+
+def test_fused_inference_batch256_hipgraph(gpu):
+    """BASELINE configs[3] at its stated size: inference-only fused forward, batch 256 per GPU (sum of nodes ~51 k,
+    4096 windows x 4 heads in Swin stage 0), captured in a hipGraph.  Replay must equal eager bit for bit, and the logits of
+    functions taken from the 256 must equal the same functions run alone at batch 2 (the size the oracle check
+    test_fused_full_size_eval_logits_vs_oracle covers) -- an eval forward has no cross-sample coupling (BatchNorm uses
+    running statistics), so any difference is an indexing / grid-range bug that only shows at this size.
+    Reference analogue: the eval loop of main_bigvul.py:371-445."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16"], batch_size=256, local_rank=0))
+    model = build_fused_model(config)
+    load_synth_into(model)
+    model = model.to(gpu).eval()
+    f = config.FUSED
+    idx = list(range(1000, 1256))
+    g, images, ids, _ = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g = g.to(gpu)
+    g.index()
+    images, ids = images.to(gpu), ids.to(gpu)
+    with torch.no_grad():
+        for _ in range(2):
+            eager = model(g, images, ids).float().clone()
+        assert eager.shape == (256, 2) and torch.isfinite(eager).all()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(g, images, ids)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(g, images, ids)
+        for _ in range(2):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.float(), eager)
+        del graph, out
+        # the same functions alone, two at a time: first pair, a middle pair, the last pair
+        for pair in ([0, 1], [127, 200], [254, 255]):
+            g2, im2, id2, _ = synthetic.make_batch([idx[i] for i in pair], config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+            g2 = g2.to(gpu)
+            g2.index()
+            small = model(g2, im2.to(gpu), id2.to(gpu)).float()
+            # identical arithmetic per function; GEMM tile boundaries move with the batch, so allow bf16 rounding noise only
+            assert float((small - eager[pair]).abs().max()) < 5e-3, (pair, small, eager[pair])
