@@ -60,9 +60,10 @@ def build(args, device, rank):
     f = config.FUSED
     idx = [rank * args.batch + i for i in range(args.batch)]
     g, images, ids, labels = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g.index()                                    # CSR index on the host, as the data loader's collate does
+    lens = (ids != 1).sum(1).to(torch.int32)     # non-pad tokens per function, counted on the host (main_bigvul.model_step_inputs)
     g = g.to(device)
-    g.index()
-    batch = (g, images.to(device), ids.to(device), labels.to(device))
+    batch = (g, images.to(device), ids.to(device), labels.to(device), lens)
     return config, model, opt, sched, batch
 
 
@@ -107,11 +108,11 @@ def main():
         for _i in range(4):
             ops.on_backward_done(f"swin.layers.{_i}", lambda _i=_i: reducer.launch_ranges(store.segment(f"swin.layers.{_i}.")))
         ops.on_backward_done("unixcoder", lambda: reducer.launch_ranges(store.segment("unixcoder.")))
-    g, images, ids, labels = batch
+    g, images, ids, labels, lens = batch
     it = [0]
 
     def step():
-        logits = model(g, images, ids)
+        logits = model(g, images, ids, seq_lens=lens)
         loss, _ = cross_entropy(logits, labels)
         loss.backward()
         reducer.finish()

@@ -57,14 +57,18 @@ int mvuld_set_gemm_p256_mode(int mode);
 int mvuld_set_gemm_p256_rows(int rows);
 
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
- * layout, contraction split over `splitk` workgroups per 128 x 128 output tile); dbias[N] += column sums of dY when non-null.
- * `ws` (optional, caller-owned, ws_bytes >= mvuld_gemm_tn_wgrad_workspace_bytes(N, K, splitk), 16-byte aligned, ZEROED ONCE by
- * the caller when allocated, then private to one stream): the splits exchange fp32 partial tiles through it and only the
- * last one to finish adds into dW; without it every split adds its partial into dW with fp32 atomics (splitk x the traffic).
+ * layout, fp32 accumulate); dbias[N] += column sums of dY when non-null.  The token contraction is split over workgroups.
+ * `ws` (optional, caller-owned, ws_bytes >= mvuld_gemm_tn_wgrad_workspace_bytes(M, N, K, splitk), 16-byte aligned, ZEROED ONCE by
+ * the caller when allocated, then private to one stream) lets the splits exchange fp32 partial tiles instead of adding
+ * every partial into dW with fp32 atomics: weights that fill 256 x 256 tiles (M % 32 == 0) take the LDS-DMA kernel of
+ * csrc/gemm_tn256.hip (its own split plan + a reduction launch; `splitk` is ignored), 2..8-way splits of the 128 x 128
+ * kernel a last-arriver reduction; everything else, and every call without `ws`, the atomic form.
  * The autograd of every nn.Linear weight/bias on the path (same call sites as mvuld_gemm_nt). */
-int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int N, int K, int splitk);   /* 0 = this shape cannot use a workspace */
+int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int M, int N, int K, int splitk);   /* 0 = no workspace form for this shape */
 int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
                         float* dbias, int splitk, void* ws, int64_t ws_bytes, mvuld_stream_t stream);
+/* 0: never route mvuld_gemm_tn_wgrad to the 256 x 256-tile kernel (A/B timing, tests); 1 (default): as described above. */
+int mvuld_set_gemm_tn256(int on);
 
 /* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
 int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);
@@ -116,6 +120,8 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
                           const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                           float* dlogit_scale, int dtype, mvuld_stream_t stream);
 
+/* mode 2 (matrix-core kernels only): mode 1 over PACKED sequences: `valid` carries cu [B+1], N = the longest sequence allowed
+ * (sizes LDS and the lse rows: lse is [B, H, N]), `res` = total packed tokens; every packed token is a valid key. */
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
  * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).
@@ -166,6 +172,18 @@ int mvuld_embed_fwd(const int64_t* ids, const int* pos, const float* word, const
                     void* out, int64_t ntok, int H, int vocab, int maxpos, int dtype, mvuld_stream_t stream);
 int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* dword, float* dposw, int64_t ntok, int H,
                     int vocab, int maxpos, int dtype, mvuld_stream_t stream);
+
+/* Packed (pad-free) token sequences.  The reference pads every function / source line to 512 tokens and masks the pad keys
+ * (unixcoder.py:33-38,56-68; data_list.py:293-299); pad rows never reach a result (masked mean, :37), so the text encoder may
+ * run on the non-pad tokens only.  cu [B+1] (int32, device): cu[b] .. cu[b+1]-1 are the packed rows of sequence b (exclusive scan
+ * of the per-sequence non-pad counts).  pack_tokens writes the packed ids, their HF position ids and rowmap[t] = b*L + l (the
+ * padded row of packed row t).  segment_mean_* = the masked mean over a packed sequence and its gradient.
+ * rows_map: scatter = 0: dst[t] = src[map[t]]; scatter = 1: dst[map[t]] = src[t]  (t < rows): unpacking to [B*L, C] and back. */
+int mvuld_pack_tokens(const int64_t* ids, const int* cu, int64_t* ids_packed, int* pos_packed, int* rowmap, int B, int L, int pad,
+                      mvuld_stream_t stream);
+int mvuld_segment_mean_fwd(const void* x, const int* cu, void* out, int B, int C, int dtype, mvuld_stream_t stream);
+int mvuld_segment_mean_bwd(const void* dout, const int* cu, void* dx, int B, int C, int dtype, mvuld_stream_t stream);
+int mvuld_rows_map(const void* src, const int* map, void* dst, int64_t rows, int C, int scatter, int dtype, mvuld_stream_t stream);
 
 /* (masked) mean over tokens: AdaptiveAvgPool1d (swin_transformer_v2.py:633) and the sentence vector (unixcoder.py:37) */
 int mvuld_mean_pool_fwd(const void* x, const int* valid, void* out, int B, int L, int C, int dtype, mvuld_stream_t stream);

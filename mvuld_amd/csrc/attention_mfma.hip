@@ -22,6 +22,8 @@
 struct AttnGeom {
     int mode, B, H, N, nW, res, ws, shift;
     float scale;
+    const int* cu;          // MODE 1, packed (varlen) sequences: cu[b] .. cu[b+1] are the token rows of sequence b; null = dense [B, N]
+    int64_t tok0;           // MODE 1: first token row of the workgroup's sequence (set inside the kernels)
 };
 
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
@@ -32,7 +34,7 @@ typedef float __attribute__((ext_vector_type(4))) f32x4_t;
 #define NEG_BIG -1.0e30f
 
 __device__ __forceinline__ int64_t am_token(const AttnGeom& g, int b, int w, int n) {
-    if (g.mode == 1) return (int64_t)b * g.N + n;
+    if (g.mode == 1) return g.tok0 + n;
     const int nwx = g.res / g.ws;
     const int sy = (w / nwx) * g.ws + n / g.ws, sx = (w % nwx) * g.ws + n % g.ws;
     int oy = sy + g.shift, ox = sx + g.shift;
@@ -46,12 +48,23 @@ __device__ __forceinline__ int am_rid(const AttnGeom& g, int s) { return s < g.r
 #define AM_PAD (1 << 30)
 __device__ __forceinline__ int am_info(const AttnGeom& g, const int* __restrict__ valid, int b, int w, int n) {
     if (n >= g.N) return AM_PAD;
-    if (g.mode == 1) return valid[b * g.N + n] ? 1 : 0;
+    if (g.mode == 1) return (valid == nullptr || valid[g.tok0 + n]) ? 1 : 0;
     const int nwx = g.res / g.ws;
     const int iy = n / g.ws, ix = n % g.ws;
     int reg = 0;
     if (g.shift > 0) reg = am_rid(g, (w / nwx) * g.ws + iy) * 3 + am_rid(g, (w % nwx) * g.ws + ix);
     return (iy * (2 * g.ws - 1) + ix) | (reg << 16);
+}
+
+// MODE 1: point the geometry at the workgroup's sequence.  Dense: rows b*N .. b*N+N-1.  Packed: rows cu[b] .. cu[b+1]-1, g.N becomes
+// the sequence's own length (<= the launch's N, which sizes LDS and the lse rows).  Returns the extent (multiple of 32) the
+// staging and key / query loops run over; 0 = empty sequence.
+__device__ __forceinline__ int am_localize(AttnGeom& g, int b, int Npad) {
+    if (g.mode != 1) return Npad;
+    if (g.cu == nullptr) { g.tok0 = (int64_t)b * g.N; return Npad; }
+    g.tok0 = g.cu[b];
+    g.N = g.cu[b + 1] - g.cu[b];
+    return min(Npad, (g.N + 31) / 32 * 32);
 }
 
 // reductions over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48 -- VALU only (v_permlane16/32_swap)
@@ -218,10 +231,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;          // lse rows keep the launch's N as their stride
+    const int Np = am_localize(g, b, Npad);
+    if (Np == 0) return;
 
-    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
-    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
         const int inf = am_info(g, valid, b, w, i);
         Kinfo[i] = MODE == 0 ? (((inf & 0xffff) << 2) | (inf & ~0xffff)) : inf;
     }
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
         for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
         for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
-        for (; kb < Npad; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
+        for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
         l = sum4g(l);
         if (qok) {
             const float inv = 1.0f / l;
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
                 for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(oacc[d][r] * inv);
                 *(uint2*)(out + tq * C + h * HD + d * 16 + 4 * fg) = o.u;
             }
-            if (fg == 0) lse[((int64_t)bw * g.H + h) * g.N + nq] = (m + __log2f(l)) * LN2;
+            if (fg == 0) lse[lse0 + nq] = (m + __log2f(l)) * LN2;
         }
     }
 }
@@ -362,10 +378,13 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
+    const int Np = am_localize(g, b, Npad);
+    if (Np == 0) return;
 
-    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, MODE == 0, 1.0f);
-    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
         const int inf = am_info(g, valid, b, w, i);
         Kinfo[i] = MODE == 0 ? (((inf & 0xffff) << 2) | (inf & ~0xffff)) : inf;
     }
@@ -413,14 +432,14 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
                 for (int ks = 0; ks < HD / 32; ++ks) { U8 o; o.v = qf[ks]; *(uint4*)(qt_out + tq * C + h * HD + ks * 32 + fg * 8) = o.u; }
             }
         }
-        const float L2q = lse[((int64_t)bw * g.H + h) * g.N + nqc] * LOG2E;
+        const float L2q = lse[lse0 + nqc] * LOG2E;
         const float Dq = qok ? delta[tq * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
         f32x4_t dq[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
         for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
-        for (; kb < Npad; kb += 32) am_dq_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
+        for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
         // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
         if (MODE == 0) {
             float qh[HD / 16][4];
@@ -755,6 +774,9 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int C = g.H * HD;
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
+    const int Np = am_localize(g, b, Npad);
+    if (Np == 0) return;
     int C0 = 0;
     float qmul = g.scale;
     if (MODE == 0) {
@@ -763,14 +785,14 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
         qmul = __expf(fminf(logit_scale[h], LN100));
     }
-    stage_tile<HD>(g, qkv, rs, h * HD, b, w, 0, Npad, Qs, MODE == 0, qmul * LOG2E);
-    stage_tile<HD>(g, dout, C, h * HD, b, w, 0, Npad, Ds, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+    stage_tile<HD>(g, qkv, rs, h * HD, b, w, 0, Np, Qs, MODE == 0, qmul * LOG2E);
+    stage_tile<HD>(g, dout, C, h * HD, b, w, 0, Np, Ds, false, 1.0f);
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
         const int inf = am_info(g, valid, b, w, i);
         Qi[i] = MODE == 0 ? ((((inf & 0xffff) + C0) << 2) | (inf & ~0xffff)) : inf;
         float L = 0.f, D = 0.f;
         if (i < g.N) {
-            L = lse[((int64_t)bw * g.H + h) * g.N + i] * LOG2E;
+            L = lse[lse0 + i] * LOG2E;
             D = delta[am_token(g, b, w, i) * g.H + h];
         }
         Ql[i] = L;
@@ -812,7 +834,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
         int qb = 0;
         for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
-        for (; qb < Npad; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
         // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc; dk was accumulated against q~ * log2(e)
         if (kok) {
 #pragma unroll
@@ -863,7 +885,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 
 // ------------------------------------------------------------------------------------------------ launchers
 static int am_check(const char* fn, int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift) {
-    MV_CHECK_ARG(mode == 0 || mode == 1, "%s: mode %d", fn, mode);
+    MV_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "%s: mode %d", fn, mode);
     MV_CHECK_ARG(B > 0 && H > 0 && N > 0 && nW > 0, "%s: empty geometry", fn);
     MV_CHECK_ARG(hd == 32 || hd == 64, "%s: head_dim %d unsupported (32|64)", fn, hd);
     if (mode == 0) {
@@ -871,6 +893,7 @@ static int am_check(const char* fn, int mode, int B, int H, int hd, int N, int n
         MV_CHECK_ARG(shift >= 0 && shift < ws, "%s: shift %d", fn, shift);
     } else {
         MV_CHECK_ARG(nW == 1, "%s: pad mode needs nW=1", fn);
+        MV_CHECK_ARG(mode == 1 || res > 0, "%s: packed mode passes the total token count in `res`", fn);
     }
     MV_CHECK_ARG((int64_t)B * nW * H * 8 < 2147483647LL, "%s: grid", fn);
     return 0;
@@ -917,8 +940,9 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
                                    float* lse, int dtype, hipStream_t stream) {
     if (am_check("attn_fwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_fwd_mfma: bf16 storage only");
-    MV_CHECK_ARG(qkv && out && lse && (mode == 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale};
+    MV_CHECK_ARG(qkv && out && lse && (mode >= 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0};
+    if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
     const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)T2 * 4;
@@ -958,11 +982,12 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     MV_CHECK_ARG(passes >= 1 && passes <= 3, "attn_bwd_mfma: passes is a mask of 1 (delta + dQ + dK/dV) and 2 (bias-table gradient)");
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
-    MV_CHECK_ARG(mode == 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale};
+    MV_CHECK_ARG(mode >= 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0};
+    int64_t ntok = (int64_t)B * nW * N;
+    if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
-    const int64_t ntok = (int64_t)B * nW * N;
     if (passes & 1)
         hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H * (hd / 8), 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
                            ws_delta, ntok, H, hd);

@@ -624,3 +624,88 @@ extern "C" int mvuld_split_bf16x3(const float* src, int64_t ld, void* dst, int64
     MV_LAUNCH_CHECK("split_bf16x3");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ packed (pad-free) token sequences
+// The reference pads every function / source line to 512 tokens (unixcoder.py:56-68, data_list.py:293-299) and masks the pad
+// keys; pad QUERY rows are computed and thrown away (the sentence vector is a masked mean, unixcoder.py:37).  Packing keeps
+// only the non-pad tokens: row cu[b] + r of the packed matrices is the r-th non-pad token of sequence b.
+// One wave per sequence: ballot + prefix popcount over 64 positions at a time.  pos = HF create_position_ids_from_input_ids.
+__global__ __launch_bounds__(64) void pack_tokens_k(const int64_t* __restrict__ ids, const int* __restrict__ cu, int64_t* __restrict__ ids_p,
+                                                    int* __restrict__ pos_p, int* __restrict__ rowmap, int L, int pad) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int base = cu[b], cap = cu[b + 1] - base;
+    int run = 0;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        const int l = l0 + lane;
+        const int64_t id = l < L ? ids[(int64_t)b * L + l] : pad;
+        const bool ok = l < L && id != pad;
+        const unsigned long long m = __ballot(ok);
+        const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && rank < cap) {                    // rank < cap always holds when cu was built from these ids
+            ids_p[base + rank] = id;
+            pos_p[base + rank] = rank + 1 + pad;
+            rowmap[base + rank] = b * L + l;
+        }
+        run += __popcll(m);
+    }
+}
+extern "C" int mvuld_pack_tokens(const int64_t* ids, const int* cu, int64_t* ids_packed, int* pos_packed, int* rowmap, int B, int L, int pad,
+                                 hipStream_t stream) {
+    MV_CHECK_ARG(ids && cu && ids_packed && pos_packed && rowmap && B > 0 && L > 0, "pack_tokens: bad args");
+    hipLaunchKernelGGL(pack_tokens_k, dim3(B), dim3(64), 0, stream, ids, cu, ids_packed, pos_packed, rowmap, L, pad);
+    MV_LAUNCH_CHECK("pack_tokens");
+    return 0;
+}
+
+// out[b] = mean of rows cu[b] .. cu[b+1]-1 (the sentence vector over a packed sequence); backward spreads dout[b] / len_b
+template <typename T>
+__global__ __launch_bounds__(256) void segment_mean_fwd_k(const T* __restrict__ x, const int* __restrict__ cu, T* __restrict__ out, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = cu[b], r1 = cu[b + 1];
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += ldf(x + (int64_t)r * C + c);
+    stf(out + (int64_t)b * C + c, s / (float)(r1 - r0));           // an empty sequence gives NaN, as the reference's 0 / 0 does
+}
+template <typename T>
+__global__ __launch_bounds__(256) void segment_mean_bwd_k(const T* __restrict__ dout, const int* __restrict__ cu, T* __restrict__ dx, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = cu[b], r1 = cu[b + 1];
+    const float v = ldf(dout + (int64_t)b * C + c) / (float)(r1 - r0);
+    for (int r = r0; r < r1; ++r) stf(dx + (int64_t)r * C + c, v);
+}
+extern "C" int mvuld_segment_mean_fwd(const void* x, const int* cu, void* out, int B, int C, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && cu && out && B > 0 && C > 0, "segment_mean_fwd: bad args");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(segment_mean_fwd_k<T>, dim3((unsigned)cdiv(C, 256), B), dim3(256), 0, stream, (const T*)x, cu, (T*)out, C));
+    MV_LAUNCH_CHECK("segment_mean_fwd");
+    return 0;
+}
+extern "C" int mvuld_segment_mean_bwd(const void* dout, const int* cu, void* dx, int B, int C, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(dout && cu && dx && B > 0 && C > 0, "segment_mean_bwd: bad args");
+    DISPATCH_T(dtype, hipLaunchKernelGGL(segment_mean_bwd_k<T>, dim3((unsigned)cdiv(C, 256), B), dim3(256), 0, stream, (const T*)dout, cu, (T*)dx, C));
+    MV_LAUNCH_CHECK("segment_mean_bwd");
+    return 0;
+}
+
+// row gather / scatter through a row map: scatter = 0: dst[t] = src[map[t]] ; scatter = 1: dst[map[t]] = src[t]   (t < T, C % 8 == 0 bf16 / % 4 f32)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_map_k(const T* __restrict__ src, const int* __restrict__ map, T* __restrict__ dst, int64_t Trows, int C,
+                                                  int scatter) {
+    constexpr int V = 16 / sizeof(T);
+    const int cpr = C / V;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Trows * cpr) return;
+    const int64_t t = i / cpr;
+    const int c = (int)(i % cpr) * V;
+    const int64_t m = map[t];
+    const int64_t s = scatter ? t : m, d = scatter ? m : t;
+    *(uint4*)(dst + d * C + c) = *(const uint4*)(src + s * C + c);
+}
+extern "C" int mvuld_rows_map(const void* src, const int* map, void* dst, int64_t rows, int C, int scatter, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(src && map && dst && rows > 0 && C > 0 && C % (dtype == MVULD_F32 ? 4 : 8) == 0, "rows_map: bad args");
+    const int cpr = C / (dtype == MVULD_F32 ? 4 : 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(rows_map_k<T>, dim3((unsigned)cdiv(rows * cpr, 256)), dim3(256), 0, stream, (const T*)src, map, (T*)dst, rows, C, scatter));
+    MV_LAUNCH_CHECK("rows_map");
+    return 0;
+}

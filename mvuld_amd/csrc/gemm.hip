@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "gemm_common.h"
+#include <atomic>
 
 template <typename TO>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, TO* C, TO* aux, int row, int col, float acc) {
@@ -1070,10 +1071,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
 // workspace of mvuld_gemm_tn_wgrad for an N x K weight: one 4-byte ticket per 128 x 128 output tile (kept at 0 between
 // launches by the kernel itself: the caller zeroes the buffer ONCE, when it allocates it) followed by splitk 64 KiB slabs per tile
 #define TN_TICKET_BYTES 4096
-extern "C" int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int N, int K, int splitk) {
+static int64_t tn128_workspace_bytes(int N, int K, int splitk) {
     const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
     if (splitk < 2 || tiles * 4 > TN_TICKET_BYTES) return 0;
     return TN_TICKET_BYTES + tiles * splitk * (int64_t)(128 * 128 * 4);
+}
+extern "C" int64_t mvuld_gemm_tn_wgrad_workspace_bytes(int M, int N, int K, int splitk) {
+    const int64_t a = tn128_workspace_bytes(N, K, splitk);
+    const int64_t b = mvuld_gemm_tn256_workspace_bytes(M, N, K);
+    const int64_t c = b > 0 ? TN_TICKET_BYTES + b : 0;
+    return a > c ? a : c;
+}
+
+// 1 (default): weights that fill 256 x 256 tiles go to the LDS-DMA kernel of gemm_tn256.hip when a workspace is given; 0: never
+static std::atomic<int> g_tn256{-1};
+extern "C" int mvuld_set_gemm_tn256(int on) {
+    g_tn256.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
 }
 
 extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K,
@@ -1085,10 +1099,18 @@ extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, i
     const int mtiles = (int)cdiv(M, TN_BM);
     if (splitk < 1) splitk = 1;
     if (splitk > mtiles) splitk = mtiles;
+    if (ws && ws_bytes > TN_TICKET_BYTES && (((uintptr_t)ws) & 15) == 0) {
+        int on = g_tn256.load(std::memory_order_relaxed);
+        if (on < 0) { const char* e = getenv("MVULD_GEMM_TN256"); on = e ? (atoi(e) != 0) : 1; g_tn256.store(on, std::memory_order_relaxed); }
+        if (on && mvuld_gemm_tn256_try(dY, ldy, X, ldx, dW, ldw, M, N, K, dbias, (char*)ws + TN_TICKET_BYTES, ws_bytes - TN_TICKET_BYTES, stream) == 0) {
+            MV_LAUNCH_CHECK("gemm_tn256");
+            return 0;
+        }
+    }
     float* slabs = nullptr;
     unsigned* tickets = nullptr;
-    if (ws && splitk > 1) {
-        const int64_t need = mvuld_gemm_tn_wgrad_workspace_bytes(N, K, splitk);
+    if (ws && splitk >= 2 && splitk <= 8 && tn128_workspace_bytes(N, K, splitk) > 0) {
+        const int64_t need = tn128_workspace_bytes(N, K, splitk);
         MV_CHECK_ARG(need > 0 && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0, "gemm_tn_wgrad: workspace too small (%lld < %lld bytes) or misaligned",
                      (long long)ws_bytes, (long long)need);
         tickets = (unsigned*)ws;

@@ -46,3 +46,8 @@ template <typename TO> __device__ __forceinline__ float dgelu_t(float x) {
 
 // persistent 256 x 256 NT kernel (gemm_p256.hip); returns 0 when it took the launch, -1 when the shape is not its to take
 int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream);
+
+// 256 x 256-tile weight-gradient kernel (gemm_tn256.hip); `ws` = slab area (no ticket block); 0 = took the launch, -1 = not its shape
+int64_t mvuld_gemm_tn256_workspace_bytes(int M, int N, int K);
+int mvuld_gemm_tn256_try(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K, float* dbias,
+                         void* ws, int64_t ws_bytes, hipStream_t stream);

@@ -1,0 +1,235 @@
+// Weight gradient  dW[N,K] += dY[M,N]^T . X[M,K]  on 256 x 256 output tiles (bf16 operands, token-major as they sit in HBM).
+//
+// The 128 x 128 kernel of gemm.hip stages its operands through VGPRs: 64 KiB of ds_write_b128 per 64-token step and CU is
+// the LDS store path's whole budget (~79 B/clk), and at 64 FLOP per byte pulled from L2 it is bandwidth-bound besides.  This
+// one mirrors gemm_p256.hip:
+//   * 8 waves (2 x 4), each 128 (n) x 64 (k) of the tile: 128 FLOP per L2 byte;
+//   * token slabs of 32 rows arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of four
+//     32 KiB stages, three slabs in flight behind counted `s_waitcnt vmcnt`, one barrier per slab;
+//   * both MFMA operands are the hardware-transposed read (ds_read_b64_tr_b16) of the row-major [32 tokens][256 columns] images;
+//     512-byte rows put every row on the same banks, so the DMA source lanes are permuted (16-byte chunk c of row r lands in
+//     slot c ^ 2(r & 7)): the 8 rows of a 32-lane half then cover all 64 banks;
+//   * the bias gradient (column sums of dY) is one more MFMA per fragment against a register of ones -- no LDS reads, no VALU;
+//   * the contraction is split over workgroups so that tiles x splits fills the chip once; each split writes its 256 KiB fp32
+//     partial in register order (1 KiB per store instruction) and a second, fully parallel kernel adds the partials into dW.
+//     (fp32 atomics straight from the accumulators would be 256 KiB per workgroup at ~50 ns per 256 bytes and CU: as long as
+//     the main loop itself.)
+// M % 32 == 0 (token counts of the model are), N % 8 == 0, K % 8 == 0; column tails are computed on clamped addresses and dropped.
+#include "gemm_common.h"
+
+typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
+
+#define T_STAGE_BYTES 32768            // dY [32][256] bf16 (16 KiB) + X [32][256] bf16 (16 KiB)
+#define T_LDS_BYTES (4 * T_STAGE_BYTES)
+#define T_SLAB_FLOATS 65536            // one 256 x 256 fp32 partial
+
+// byte offset of element (row r, column c) of a [32][256] bf16 image whose 16-byte chunks are XOR-swizzled by the row
+__device__ __forceinline__ int t_off(int r, int c) { return r * 512 + ((((c >> 3) ^ (2 * (r & 7)))) << 4) + (c & 7) * 2; }
+
+__global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ dY, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
+                                                       int M, int N, int K, int tiles_k, int nsplit, int per, float* __restrict__ slabs,
+                                                       float* __restrict__ dW, int64_t ldw, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef __attribute__((address_space(1))) const void* glb_vp;
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    // split-major order: the splits of one tile sit next to each other, workgroups b, b+8, ... share an XCD
+    const int tl = blockIdx.x / nsplit, ks = blockIdx.x % nsplit;
+    const int tn = tl / tiles_k, tk = tl % tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int mslabs = M / 32;
+    const int s0 = ks * per, s1 = min(mslabs, s0 + per);
+    const int nk = s1 - s0;                              // >= 1 by construction of nsplit / per on the host
+
+    // LDS-DMA map: one instruction = 1 KiB = 2 image rows; lane l -> row l >> 5, slot l & 31, fetching chunk slot ^ 2(row & 7).
+    // Wave w issues pieces 2w, 2w+1 (rows 4w .. 4w+3) of the dY image and of the X image.
+    const bf16* ga[2];
+    const bf16* gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 2 + (lane >> 5);
+        const int ch = (lane & 31) ^ (2 * (r & 7));
+        const int ca = n0 + ch * 8, cb = k0 + ch * 8;
+        ga[i] = dY + (int64_t)(s0 * 32 + r) * ldy + (ca < N ? ca : 0);
+        gb[i] = X + (int64_t)(s0 * 32 + r) * ldx + (cb < K ? cb : 0);
+    }
+    const int64_t stepa = 32 * ldy, stepb = 32 * ldx;
+    int issued = 0;
+    auto issue_one = [&]() {
+        if (issued < nk) {
+            char* st = smem + (issued & 3) * T_STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((glb_vp)(ga[i] + issued * stepa), (lds_vp)(st + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vp)(gb[i] + issued * stepb), (lds_vp)(st + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+            }
+            ++issued;
+        }
+    };
+    issue_one();
+    issue_one();
+    issue_one();
+
+    // transposed-read addresses (constant over the loop).  Fragment of 16 columns col0.. over the 32 rows of a stage:
+    // k-slot (g, j<4) <-> row 4g+j, (g, j>=4) <-> row 16+4g+j-4 on BOTH operands; lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3.
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    int oa[8], ob[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oa[i] = t_off(4 * fg + q, wr * 128 + i * 16 + 4 * pp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = 16384 + t_off(4 * fg + q, wc * 64 + j * 16 + 4 * pp);
+
+    f32x4_t acc[8][4], accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = dbias && tk == 0 && wc == 0;   // wave-uniform
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = nk - 1 - kt;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // slab kt visible to every wave; every wave is done with slab kt - 1
+        issue_one();                                     // slab kt + 3 refills the stage slab kt - 1 occupied
+        const char* st = smem + (kt & 3) * T_STAGE_BYTES;
+        bf16x8_t fa[8], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + ob[j]));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + ob[j] + 16 * 512));
+            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + oa[i]));
+            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + oa[i] + 16 * 512));
+            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        }
+    }
+
+    // bias gradient: every column of accb[i] holds sum_m dY[m][n]; lanes of column 0 add the split's share
+    if (do_bias && fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 128 + i * 16 + 4 * fg + r;
+                if (n < N) atomicAdd(dbias + n, accb[i][r]);
+            }
+    }
+    // acc[i][j][r] = dW[n0 + wr*128 + i*16 + 4*fg + r][k0 + wc*64 + j*16 + fr]
+    if (nsplit > 1) {
+        float* mine = slabs + ((size_t)tl * nsplit + ks) * T_SLAB_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4_t*)(mine + ((wave * 32 + i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wr * 128 + i * 16 + 4 * fg + r, k = k0 + wc * 64 + j * 16 + fr;
+                    if (n < N && k < K) atomicAdd(dW + (int64_t)n * ldw + k, acc[i][j][r]);
+                }
+    }
+}
+
+// dW += sum over splits of the partial tiles (register-order slabs): one thread per (tile, wave, fragment, lane) float4
+__global__ __launch_bounds__(256) void gemm_tn256_reduce_k(const float* __restrict__ slabs, int nsplit, int tiles_k, int N, int K,
+                                                           float* __restrict__ dW, int64_t ldw) {
+    const int tl = blockIdx.x >> 6;                      // 64 blocks of 256 threads per tile
+    const int pos = ((blockIdx.x & 63) << 8) + threadIdx.x;          // 0 .. 16383
+    const int lane = pos & 63, frag = (pos >> 6) & 31, wave = pos >> 11;
+    const int i = frag >> 2, j = frag & 3, wr = wave >> 2, wc = wave & 3, fr = lane & 15, fg = lane >> 4;
+    const float* p = slabs + (size_t)tl * nsplit * T_SLAB_FLOATS + (size_t)pos * 4;
+    f32x4_t s = *(const f32x4_t*)p;
+    for (int k = 1; k < nsplit; ++k) s += *(const f32x4_t*)(p + (size_t)k * T_SLAB_FLOATS);
+    const int n0 = (tl / tiles_k) * 256, k0 = (tl % tiles_k) * 256;
+    const int kk = k0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 128 + i * 16 + 4 * fg + r;
+        if (n < N && kk < K) atomicAdd(dW + (int64_t)n * ldw + kk, s[r]);
+    }
+}
+
+static int tn256_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
+// split plan of the 256 x 256-tile kernel: 0 splits = shape not eligible
+static void tn256_plan(int M, int N, int K, int& nsplit, int& per) {
+    nsplit = 0;
+    per = 0;
+    if (M % 32 != 0 || M < 256) return;
+    const int64_t tiles = cdiv(N, 256) * cdiv(K, 256);
+    // fewer than 8 tiles would mean > 32 splits: the partial slabs (256 KiB each) then cost more than the 128 x 128 kernel's atomics
+    // (measured, tools/gemm_shapes.py: 512 x 512 and 256 x 256 weights lose, 768 x 768 breaks even, everything wider wins 15-25 %)
+    if (tiles < 8) return;
+    // most of every tile must be real weight: (padded area) <= 1.25 x (N x K)
+    if (cdiv(N, 256) * 256 * cdiv(K, 256) * 256 * 4 > (int64_t)N * K * 5) return;
+    const int mslabs = M / 32;
+    int want = (int)(tn256_num_cus() / tiles);
+    if (want < 1) want = 1;
+    if (want > mslabs / 8) want = mslabs / 8 > 0 ? mslabs / 8 : 1;      // at least 8 ring steps per split
+    per = (int)cdiv(mslabs, want);
+    nsplit = (int)cdiv(mslabs, per);                     // every split non-empty
+}
+
+int64_t mvuld_gemm_tn256_workspace_bytes(int M, int N, int K) {
+    int nsplit, per;
+    tn256_plan(M, N, K, nsplit, per);
+    if (nsplit < 1) return 0;
+    return nsplit > 1 ? cdiv(N, 256) * cdiv(K, 256) * (int64_t)nsplit * T_SLAB_FLOATS * 4 : 16;
+}
+
+// returns 0 when it took the launch, -1 when the shape (or the workspace) is not its to take
+int mvuld_gemm_tn256_try(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int M, int N, int K, float* dbias,
+                         void* ws, int64_t ws_bytes, hipStream_t stream) {
+    int nsplit, per;
+    tn256_plan(M, N, K, nsplit, per);
+    if (nsplit < 1) return -1;
+    const int64_t need = mvuld_gemm_tn256_workspace_bytes(M, N, K);
+    if (nsplit > 1 && (!ws || ws_bytes < need || (((uintptr_t)ws) & 15) != 0)) return -1;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_k, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const int tiles_k = (int)cdiv(K, 256);
+    const int tiles = (int)(cdiv(N, 256) * tiles_k);
+    hipLaunchKernelGGL(gemm_tn256_k, dim3(tiles * nsplit), dim3(512), T_LDS_BYTES, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, M, N, K,
+                       tiles_k, nsplit, per, (float*)ws, dW, ldw, dbias);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(gemm_tn256_reduce_k, dim3(tiles * 64), dim3(256), 0, stream, (const float*)ws, nsplit, tiles_k, N, K, dW, ldw);
+    return 0;
+}

@@ -39,7 +39,9 @@ class SyntheticBigVul(Dataset):
 
 def collate(samples):
     gs, a, b, y = zip(*samples)
-    return batch_graphs(list(gs)), torch.stack(a), torch.stack(b), torch.tensor(y, dtype=torch.int64)
+    g = batch_graphs(list(gs))
+    g.index()          # CSR by destination / by source built here, on the loader's CPU side: BatchedGraph.to() carries it to the device
+    return g, torch.stack(a), torch.stack(b), torch.tensor(y, dtype=torch.int64)
 
 
 def _world():

@@ -93,9 +93,17 @@ def build_fused_model(config):
     return Multi_DefectModel_new_GCN(config=config, act_dtype=ad)
 
 
-def model_step_inputs(batch, device):
+def model_step_inputs(batch, device, pad_token_id=1):
+    """Host batch -> device inputs of one step: (g, a, b, target, kwargs).  For the fused model (`b` = token ids) the per-function
+    count of non-pad tokens is taken here, while the ids are still on the host: the text encoder then runs pad-free
+    (models/unixcoder.py: encode_packed) without a device -> host round trip.  The graph's CSR index rides along (built in collate)."""
     g, a, b, target = batch
-    return g.to(device), a.to(device, non_blocking=True), b.to(device, non_blocking=True), target.to(device, non_blocking=True)
+    kw = {}
+    if b.dtype == torch.int64 and b.dim() == 2 and not b.is_cuda:
+        kw["seq_lens"] = (b != pad_token_id).sum(1).to(torch.int32)
+    if g._index is None and not g.src.is_cuda:
+        g.index()
+    return g.to(device), a.to(device, non_blocking=True), b.to(device, non_blocking=True), target.to(device, non_blocking=True), kw
 
 
 def myMain(config, args, device):
@@ -188,8 +196,8 @@ def train_one_epoch(config, model, criterion, data_loader, optimizer, epoch, mix
     start = end = time.time()
     acc = max(1, config.TRAIN.ACCUMULATION_STEPS)
     for idx, batch in enumerate(data_loader):
-        g, a, b, targets = model_step_inputs(batch, device)
-        outputs = model(g, a, b)
+        g, a, b, targets, kw = model_step_inputs(batch, device)
+        outputs = model(g, a, b, **kw)
         # CrossEntropyLoss (:298) divided by the accumulation steps (:333); probs = softmax (:330)
         loss, probs = cross_entropy(outputs, targets, loss_scale=1.0 / acc)
         update = (idx + 1) % acc == 0
@@ -230,8 +238,8 @@ def validate(config, data_loader, model, device):
     outs, probs_all, targets_all = [], [], []
     end = time.time()
     for idx, batch in enumerate(data_loader):
-        g, a, b, targets = model_step_inputs(batch, device)
-        outputs = model(g, a, b)
+        g, a, b, targets, kw = model_step_inputs(batch, device)
+        outputs = model(g, a, b, **kw)
         loss, probs = cross_entropy(outputs, targets)
         outs.append(outputs.float()); probs_all.append(probs.float()); targets_all.append(targets.float())
         acc1, _ = accuracy(outputs, targets, topk=(1, 2))

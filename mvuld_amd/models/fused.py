@@ -39,19 +39,24 @@ class FusedMVulD(nn.Module):
     def no_weight_decay_keywords(self):
         return self.swin.no_weight_decay_keywords()
 
-    def forward(self, g, images, source_ids):
+    def forward(self, g, images, source_ids, seq_lens=None):
         """The two encoders are independent until the head: the text encoder runs on a second HIP stream so its kernels fill
         the tails of the image encoder's launches (and vice versa); autograd replays each branch's backward on the stream its
         forward ran on.  The side stream is joined before the head and, in backward, when the text encoder's first op has
         launched its last kernel (its parameter gradients are atomics into the flat store, invisible to autograd's own
-        stream bookkeeping).  MVULD_CONCURRENT=0, or the per-launch timing mode, keeps everything on one stream."""
+        stream bookkeeping).  MVULD_CONCURRENT=0, or the per-launch timing mode, keeps everything on one stream.
+        seq_lens (optional, host int tensor [B]): non-pad tokens per function; with it the text encoder runs pad-free on the packed
+        tokens (same sentence vectors: pad rows never reach them, unixcoder.py:35-37); MVULD_PACK_TEXT=0 ignores it."""
         from .. import hip, ops
         concurrent = images.is_cuda and os.environ.get("MVULD_CONCURRENT", "1") != "0" and not hip.TIMING.enabled
+        if os.environ.get("MVULD_PACK_TEXT", "1") == "0":
+            seq_lens = None
+        self.unixcoder.return_tokens = False                           # only the sentence vector is read here
         if not concurrent:
             ops.WGRAD_STREAM[0] = None
             ops.on_backward_done("unixcoder", None, key="fused-join")
             img = self.swin.forward_features(images)                   # [B,1024]
-            _, txt = self.unixcoder.get_xcode_vec(source_ids)          # [B,768]
+            _, txt = self.unixcoder.get_xcode_vec(source_ids, seq_lens)  # [B,768]
             hfeat = self.head.forward_graph(g)
         else:
             main = torch.cuda.current_stream(images.device)
@@ -80,7 +85,7 @@ class FusedMVulD(nn.Module):
             # enqueued at once, the image encoder next and the text encoder last -- whose first op, the last side-stream
             # work of the step, fires the join below.
             with torch.cuda.stream(side):
-                _, txt = self.unixcoder.get_xcode_vec(source_ids)
+                _, txt = self.unixcoder.get_xcode_vec(source_ids, seq_lens)
             img = self.swin.forward_features(images)
             with torch.cuda.stream(side):
                 hfeat = self.head.forward_graph(g)

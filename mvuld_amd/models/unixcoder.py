@@ -76,9 +76,94 @@ class _EmbedFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _PackEmbedFn(torch.autograd.Function):
+    """Packed variant of _EmbedFn: only the non-pad tokens are embedded; row cu[b] + r of the result is the r-th non-pad token of
+    sequence b (the reference computes the pad rows too and never uses them: unixcoder.py:35-37)."""
+
+    @staticmethod
+    def forward(ctx, word_w, ids, cu, T, emb, act_dtype):
+        hip.require_gpu(ids)
+        B, L = ids.shape
+        cfg = emb.config
+        H = cfg.hidden_size
+        ids = ids.contiguous()
+        ids_p = torch.empty((T,), dtype=torch.int64, device=ids.device)
+        pos_p = torch.empty((T,), dtype=torch.int32, device=ids.device)
+        rowmap = torch.empty((T,), dtype=torch.int32, device=ids.device)
+        call("pack_tokens", ptr(ids), ptr(cu), ptr(ids_p), ptr(pos_p), ptr(rowmap), B, L, cfg.pad_token_id)
+        raw = torch.empty((T, H), dtype=act_dtype, device=ids.device)
+        call("embed_fwd", ptr(ids_p), ptr(pos_p), ptr(emb.word_embeddings.weight), ptr(emb.position_embeddings.weight),
+             ptr(emb.token_type_embeddings.weight), ptr(raw), T, H, cfg.vocab_size, cfg.max_position_embeddings, dt(raw))
+        y, mean, rstd, _ = ops.layernorm_fwd(raw, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data, cfg.layer_norm_eps)
+        ctx.save_for_backward(ids_p, pos_p, raw, mean, rstd)
+        ctx.emb = emb
+        ctx.mark_non_differentiable(rowmap)
+        return y, rowmap
+
+    @staticmethod
+    def backward(ctx, dy, _drow):
+        ids_p, pos_p, raw, mean, rstd = ctx.saved_tensors
+        emb = ctx.emb
+        cfg = emb.config
+        H = cfg.hidden_size
+        draw = ops.layernorm_bwd(dy.contiguous(), raw, emb.LayerNorm.weight, emb.LayerNorm.bias, mean, rstd)
+        call("embed_bwd", ptr(ids_p), ptr(pos_p), ptr(draw), ptr(ops.grad_of(emb.word_embeddings.weight)),
+             ptr(ops.grad_of(emb.position_embeddings.weight)), ids_p.numel(), H, cfg.vocab_size, cfg.max_position_embeddings, dt(draw))
+        ops.colsum_into(draw, ops.grad_of(emb.token_type_embeddings.weight)[0])
+        ops.fire_backward_done("unixcoder")
+        return None, None, None, None, None, None
+
+
+class _SegmentMeanFn(torch.autograd.Function):
+    """Sentence vector over packed tokens: mean of rows cu[b] .. cu[b+1]-1  (= (tok * mask).sum(1) / mask.sum(-1), unixcoder.py:37)."""
+
+    @staticmethod
+    def forward(ctx, tok, cu, B):
+        H = tok.shape[1]
+        out = torch.empty((B, H), dtype=tok.dtype, device=tok.device)
+        call("segment_mean_fwd", ptr(tok), ptr(cu), ptr(out), B, H, dt(tok))
+        ctx.save_for_backward(cu)
+        ctx.dims = (tok.shape[0], B, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (cu,) = ctx.saved_tensors
+        T, B, H = ctx.dims
+        dx = torch.empty((T, H), dtype=dout.dtype, device=dout.device)
+        call("segment_mean_bwd", ptr(dout.contiguous()), ptr(cu), ptr(dx), B, H, dt(dx))
+        return dx, None, None
+
+
+class _UnpackFn(torch.autograd.Function):
+    """Packed rows -> the reference's padded [B*L, H] layout (pad rows zero; the reference leaves unused values there)."""
+
+    @staticmethod
+    def forward(ctx, tok, rowmap, rows):
+        out = torch.zeros((rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
+        call("rows_map", ptr(tok), ptr(rowmap), ptr(out), tok.shape[0], tok.shape[1], 1, dt(tok))
+        ctx.save_for_backward(rowmap)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rowmap,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty((rowmap.shape[0], dout.shape[1]), dtype=dout.dtype, device=dout.device)
+        call("rows_map", ptr(dout), ptr(rowmap), ptr(dx), rowmap.shape[0], dout.shape[1], 0, dt(dout))
+        return dx, None, None
+
+
+class PackedSeqs:
+    """cu_seqlens of a packed batch: `cu` int32 [B+1] on the device, total tokens, and the sum of squared lengths."""
+
+    def __init__(self, cu, total, sumsq):
+        self.cu, self.total, self.sumsq = cu, total, sumsq
+
+
 class _LayerFn(torch.autograd.Function):
     """One post-LN transformer block (HF RobertaLayer): fused QKV -> pad-masked attention -> dense ->
-    LN(. + x) -> dense+GELU -> dense -> LN(. + x1)."""
+    LN(. + x) -> dense+GELU -> dense -> LN(. + x1).  `valid` is the [B, L] pad mask, or a PackedSeqs for pad-free rows."""
 
     @staticmethod
     def forward(ctx, x, valid, layer, B, L):
@@ -87,7 +172,11 @@ class _LayerFn(torch.autograd.Function):
         ad = x.dtype
         sa = layer.attention.self
         qkv = ops.gemm_nt(x, ops.weight(sa.qkv_weight, ad), bias=sa.qkv_bias.data)
-        geom = ops.AttnGeom(1, B, nh, H // nh, L, 1, 0, 0, 0, 1.0 / math.sqrt(H // nh))
+        if isinstance(valid, PackedSeqs):
+            geom = ops.AttnGeom(2, B, nh, H // nh, L, 1, valid.total, 0, 0, 1.0 / math.sqrt(H // nh), sumsq=valid.sumsq)
+            valid = valid.cu
+        else:
+            geom = ops.AttnGeom(1, B, nh, H // nh, L, 1, 0, 0, 0, 1.0 / math.sqrt(H // nh))
         cx, lse = ops.attn_fwd(geom, qkv, valid=valid)
         ao = layer.attention.output
         a = ops.gemm_nt(cx, ops.weight(ao.dense.weight, ad), bias=ao.dense.bias.data)
@@ -248,6 +337,34 @@ class RobertaModel(nn.Module):
             x = _LayerFn.apply(x, valid, layer, B, L)
         return x, valid
 
+    def can_pack(self):
+        return self.act_dtype == torch.bfloat16 and ops.ATTN_IMPL[0] == "auto"
+
+    @staticmethod
+    def pack_plan(seq_lens, device, L):
+        """PackedSeqs (device cu_seqlens + host totals) from host-side per-sequence token counts.  Build it once outside a
+        hipGraph capture and pass it as `seq_lens`: the forward then does no host-side work."""
+        lens = torch.as_tensor(seq_lens, dtype=torch.int64).view(-1).cpu()
+        assert int(lens.max()) <= L and int(lens.min()) >= 0, "seq_lens out of range"
+        cu_host = torch.zeros(lens.numel() + 1, dtype=torch.int32)
+        cu_host[1:] = torch.cumsum(lens, 0)
+        T = int(cu_host[-1])
+        assert T > 0, "every sequence is empty"
+        return PackedSeqs(cu_host.to(device), T, float((lens * lens).sum()))
+
+    def encode_packed(self, source_ids, seq_lens):
+        """Pad-free encoder pass.  seq_lens: per-sequence count of non-pad tokens, a HOST int tensor / list (the data loader
+        has the ids on the host anyway: counting there avoids a device -> host sync here).
+        -> (tokens [T, H] packed, PackedSeqs, rowmap int32 [T] = padded row b*L + l of every packed row)"""
+        B, L = source_ids.shape
+        packed = seq_lens if isinstance(seq_lens, PackedSeqs) else self.pack_plan(seq_lens, source_ids.device, L)
+        assert packed.cu.numel() == B + 1, "seq_lens does not match source_ids"
+        T = packed.total
+        x, rowmap = _PackEmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, packed.cu, T, self.embeddings, self.act_dtype)
+        for layer in self.encoder.layer:
+            x = _LayerFn.apply(x, packed, layer, B, L)
+        return x, packed, rowmap
+
     def forward(self, source_ids, attention_mask=None):
         B, L = source_ids.shape
         x, _ = self.encode(source_ids)
@@ -263,10 +380,18 @@ class MyUniXcoder(nn.Module):
         self.tokenize = tokenize
         self.classifier = nn.Linear(config.hidden_size, 2)
         self.max_source_length = 512
+        self.return_tokens = True        # False: get_xcode_vec skips unpacking the token embeddings (the fused model reads only `sent`)
 
-    def get_xcode_vec(self, source_ids):
-        """Token embeddings [B,L,H] and sentence embeddings [B,H] (masked mean over non-pad tokens)."""
+    def get_xcode_vec(self, source_ids, seq_lens=None):
+        """Token embeddings [B,L,H] and sentence embeddings [B,H] (masked mean over non-pad tokens).
+        With `seq_lens` (host-side counts of non-pad tokens per sequence) the encoder runs pad-free on the packed tokens:
+        identical sentence vectors and non-pad token rows; the pad rows of the token output are zero."""
         B, L = source_ids.shape
+        if seq_lens is not None and self.encoder.can_pack():
+            tok, packed, rowmap = self.encoder.encode_packed(source_ids, seq_lens)
+            sent = _SegmentMeanFn.apply(tok, packed.cu, B)
+            full = _UnpackFn.apply(tok, rowmap, B * L).view(B, L, -1) if self.return_tokens else None
+            return full, sent
         tok, valid = self.encoder.encode(source_ids)
         sent = _MaskedMeanFn.apply(tok, valid, B, L)
         return tok.view(B, L, -1), sent

@@ -227,9 +227,7 @@ def _tn_workspace(device, nbytes):
 
 
 def _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk):
-    # measured (tools/gemm_shapes.py): the last-arriver reduction wins 3-5 % up to ~8 splits (the wide weights of stage 2/3 and of the
-    # text encoder) and loses beyond (its serial slab reads grow with the split count: small weights x 400 k tokens)
-    ws = _tn_workspace(dy.device, hip.LIB.fn("mvuld_gemm_tn_wgrad_workspace_bytes")(N, K, splitk)) if (USE_TN_SLABS[0] and 2 <= splitk <= 8) else None
+    ws = _tn_workspace(dy.device, hip.LIB.fn("mvuld_gemm_tn_wgrad_workspace_bytes")(M, N, K, splitk)) if USE_TN_SLABS[0] else None
     call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk,
          ptr(ws), ws.numel() if ws is not None else 0)
 
@@ -375,9 +373,10 @@ def dropout(x, p, seed):
 class AttnGeom:
     """Geometry of one fused-attention call (see include/mvuld_hip.h)."""
 
-    def __init__(self, mode, B, H, hd, N, nW=1, res=0, ws=0, shift=0, scale=1.0):
+    def __init__(self, mode, B, H, hd, N, nW=1, res=0, ws=0, shift=0, scale=1.0, sumsq=0):
         self.mode, self.B, self.H, self.hd, self.N, self.nW = mode, B, H, hd, N, nW
         self.res, self.ws, self.shift, self.scale = res, ws, shift, scale
+        self.sumsq = sumsq              # mode 2: sum of squared sequence lengths (algorithmic FLOP count of the instrumented step)
 
     def args(self):
         return (self.mode, self.B, self.H, self.hd, self.N, self.nW, self.res, self.ws, self.shift, float(self.scale))
@@ -392,6 +391,8 @@ def _mfma_attn_ok(g: AttnGeom, dtype):
     need = max(2 * npad * (g.hd + 8) * 2 + npad * 4 + 32 + 2 * t2 * 4, 2 * npad * (g.hd + 8) * 2 + npad * 12 + t2 * 4)
     if g.mode == 0 and (g.hd != 32 or g.ws > 32):
         return False
+    if g.mode == 2 and need > 160 * 1024:
+        raise RuntimeError(f"packed attention: sequences of up to {g.N} tokens do not fit the matrix-core kernel's LDS")
     return need <= 160 * 1024
 
 
@@ -400,7 +401,9 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     out = torch.empty((tokens, g.H * g.hd), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((g.B * g.nW * g.H * g.N,), dtype=torch.float32, device=qkv.device)
     name = "attn_fwd_mfma" if _mfma_attn_ok(g, qkv.dtype) else "attn_fwd_simple"
-    hip.TIMING.annotate(name, 4.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
+    if g.mode == 2 and name != "attn_fwd_mfma":
+        raise RuntimeError("packed (mode 2) attention exists on the matrix-core path only (bf16)")
+    hip.TIMING.annotate(name, 4.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
     call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
     return out, lse
 
@@ -414,7 +417,7 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
     if _mfma_attn_ok(g, qkv.dtype):
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
         qt = torch.empty((qkv.shape[0], g.H * g.hd), dtype=torch.bfloat16, device=qkv.device) if g.mode == 0 else None
-        hip.TIMING.annotate("attn_bwd_mfma", 14.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)
+        hip.TIMING.annotate("attn_bwd_mfma", 14.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
         args = (*g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
                 ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt))
         wg = wgrad_stream_for_current() if g.mode == 0 else None

@@ -519,20 +519,24 @@ def test_embed_im2col_patchmerge_dropout(gpu, dtype):
     assert abs(float(d1.float().mean()) - 1.0) < 0.02
 
 
-@pytest.mark.parametrize("slabs", [True, False])
-@pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (1000, 384, 136), (777, 72, 200), (20000, 256, 512), (16384, 776, 392)])
-def test_gemm_tn_wgrad(gpu, M, N, K, slabs):
-    """dW += dY^T X and db += colsum(dY) through the transpose-free matrix-core kernel (bf16 operands); the split contraction is
-    combined through the slab workspace (last-arriving workgroup reduces; tickets must be back at zero for the next launch on the
-    stream: three launches in a row accumulate three times) or, without a workspace, by fp32 atomics from every split."""
-    from mvuld_amd import ops
+@pytest.mark.parametrize("mode", ["tn256", "slab128", "atomic"])
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (1000, 384, 136), (777, 72, 200), (20000, 256, 512), (16384, 776, 392),
+                                   (16384, 768, 768), (6272, 1000, 760), (25088, 512, 2048), (2048, 256, 256)])
+def test_gemm_tn_wgrad(gpu, M, N, K, mode):
+    """dW += dY^T X and db += colsum(dY) through the transpose-free matrix-core kernels (bf16 operands).  Three ways of combining the
+    split token contraction: "tn256" = the 256 x 256-tile LDS-DMA kernel with slab partials + reduction launch where the shape
+    fills its tiles (M % 32 == 0; the others fall through), "slab128" = 128 x 128 tiles with the last-arriver slab reduction
+    (tickets must be back at zero for the next launch on the stream: three launches accumulate three times), "atomic" = fp32
+    atomics from every split."""
+    from mvuld_amd import ops, hip
     dy, x = rt(T("tn_dy", (M, N)), torch.bfloat16), rt(T("tn_x", (M, K)), torch.bfloat16)
     w = torch.nn.Parameter(torch.zeros(N, K, device=gpu))
     b = torch.nn.Parameter(torch.zeros(N, device=gpu))
     w.grad = torch.ones(N, K, device=gpu)
     b.grad = torch.ones(N, device=gpu)
     gdy, gx = dev(dy, torch.bfloat16), dev(x, torch.bfloat16)
-    ops.USE_TN_SLABS[0] = slabs
+    ops.USE_TN_SLABS[0] = mode != "atomic"
+    hip.LIB.fn("mvuld_set_gemm_tn256")(1 if mode == "tn256" else 0)
     try:
         ops.linear_wgrad(gdy, gx, w, b)
         ref = dy.t() @ x
@@ -541,5 +545,7 @@ def test_gemm_tn_wgrad(gpu, M, N, K, slabs):
         ops.linear_wgrad(gdy, gx, w, b)
         ops.linear_wgrad(gdy, gx, w, b)
         assert rel(w.grad, 3.0 * ref + 1.0) < 2e-3
+        assert rel(b.grad, 3.0 * dy.sum(0) + 1.0) < 2e-3
     finally:
         ops.USE_TN_SLABS[0] = True
+        hip.LIB.fn("mvuld_set_gemm_tn256")(1)

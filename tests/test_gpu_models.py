@@ -130,6 +130,59 @@ def test_unixcoder_sentence_vs_golden(gpu, dtype, name, kw, L, lens):
     assert e < (1e-3 if dtype == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("name,kw,L,lens", [("roberta_tiny", ROB_TINY, 128, [128, 77, 5]), ("roberta_base512", {}, 512, [512, 301])])
+def test_unixcoder_packed_sentence_vs_golden(gpu, name, kw, L, lens):
+    """The pad-free (packed, varlen-attention) text encoder against the same reference-derived goldens as the padded one: the
+    sentence vector only ever sees non-pad tokens (unixcoder.py:35-37), so dropping the pad rows must not move it.  Token rows:
+    packed == padded at every non-pad position, zero at the pad positions."""
+    m, _, rc = _unix(kw, torch.bfloat16, gpu)
+    m.eval()
+    ids = _rob_ids(rc.vocab_size, L, lens, name)
+    with torch.no_grad():
+        tokp, sent = m.get_xcode_vec(ids.to(gpu), seq_lens=torch.tensor(lens))
+        tokd, sent_d = m.get_xcode_vec(ids.to(gpu))
+    ref = torch.from_numpy(golden(name)["sent"])
+    e = rel(sent, ref)
+    print(f"[{name} packed] rel err vs golden = {e:.3e}, vs padded path {rel(sent, sent_d):.3e}")
+    assert e < 3e-2
+    assert rel(sent, sent_d) < 1e-2
+    for b, n in enumerate(lens):
+        assert rel(tokp[b, :n], tokd[b, :n]) < 2e-2
+        assert float(tokp[b, n:].abs().max()) == 0.0 if n < L else True
+
+
+def test_unixcoder_packed_gradients_vs_oracle(gpu):
+    """Backward of the packed path (varlen dQ / dK,dV passes, packed embedding scatter, segment-mean gradient) vs oracle autograd."""
+    from oracle import roberta_ref
+    m, sd, rc = _unix(ROB_TINY, torch.bfloat16, gpu)
+    m.train()
+    lens = [128, 77, 5, 33]
+    ids = _rob_ids(rc.vocab_size, 128, lens, "roberta_tiny_p")
+    wv = synth.tensor("rob/gradw4", (4, 128))
+    cfg = roberta_ref.RobertaCfg(vocab_size=1000, hidden_size=128, num_layers=2, num_heads=2, intermediate_size=512, max_position=130)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, sr = roberta_ref.unixcoder_sentence(sdr, ids, cfg)
+    (sr * wv).sum().backward()
+    m.return_tokens = False
+    _, s = m.get_xcode_vec(ids.to(gpu), seq_lens=lens)
+    (s.float() * wv.to(gpu)).sum().backward()
+    assert rel(s, sr) < 3e-2
+    worst = []
+    for n, p in m.named_parameters():
+        if not p.requires_grad or n.startswith("classifier"):
+            continue
+        if n.endswith("qkv_weight") or n.endswith("qkv_bias"):
+            base = n[:-len("qkv_weight")] if n.endswith("qkv_weight") else n[:-len("qkv_bias")]
+            suf = "weight" if n.endswith("qkv_weight") else "bias"
+            g_ref = torch.cat([sdr[f"{base}{q}.{suf}"].grad for q in ("query", "key", "value")], 0)
+        else:
+            g_ref = sdr[n].grad
+        worst.append((rel_l2(p.grad, g_ref), n))
+    worst.sort(reverse=True)
+    print("[unixcoder packed grads] worst: " + ", ".join(f"{n}={e:.2e}" for e, n in worst[:6]))
+    assert worst[0][0] < 8e-2, worst[:6]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_unixcoder_gradients_vs_oracle(gpu, dtype):
     from oracle import roberta_ref
