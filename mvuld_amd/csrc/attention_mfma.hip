@@ -148,13 +148,31 @@ __device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int ld, int d0, int 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
-// log2-domain score fix-up of one element.  tabq = (char*)tab + 4*bq  (MODE 0)
-template <int MODE, bool MASK, bool TAIL>
-__device__ __forceinline__ float am_fix(float s, int ki, const char* tabq, int regq, int vq) {
-    float v;
+// Score fix-ups.  The continuous position bias does not cost a VALU add per score: it is the INITIAL ACCUMULATOR of the S = K.Q^T
+// MFMA (am_bias4).  A lane's four accumulator rows are four consecutive window positions n0 .. n0+3 with n0 % 4 == 0; when the
+// window side is a multiple of 4 (G4) they lie in one window row, so their table entries are adjacent words: one address and two
+// ds_read2_b32 instead of four address computations and four ds_read_b32.  tabx + offset: the forward / dQ passes (keys on the rows)
+// keep the table reversed so that the words ascend with the key; the dK/dV pass (queries on the rows) uses it as it is.
+template <int MODE, bool MASK, bool TAIL, bool G4>
+__device__ __forceinline__ f32x4_t am_bias4(const int (&ki)[4], const char* tabx) {
+    f32x4_t b = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 0) {
-        const int off = (MASK || TAIL) ? (ki & 0xffff) : ki;
-        v = s + *(const float*)(tabq - off);
+        if (G4) {
+            const float* a = (const float*)(tabx + ((MASK || TAIL) ? (ki[0] & 0xffff) : ki[0]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = a[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = *(const float*)(tabx + ((MASK || TAIL) ? (ki[r] & 0xffff) : ki[r]));
+        }
+    }
+    return b;
+}
+// what is left per score after the MFMA (s already holds q.k + bias): shift mask / pad mask / tail padding
+template <int MODE, bool MASK, bool TAIL>
+__device__ __forceinline__ float am_mask(float s, int ki, int regq, int vq) {
+    float v = s;
+    if (MODE == 0) {
         if (MASK) v = (((ki >> 16) & 0xff) != regq) ? v - 100.0f * LOG2E : v;
     } else {
         v = (vq & ki & 1) ? s : s - 10000.0f * LOG2E;
@@ -163,48 +181,45 @@ __device__ __forceinline__ float am_fix(float s, int ki, const char* tabq, int r
     return v;
 }
 
-// one block of NT 16-key tiles (NT = 4: 64 keys, NT = 2: 32 keys) of the online-softmax forward
-template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+// one block of NT 16-key tiles (NT = 4: 64 keys, NT = 2: 32 keys) of the online-softmax forward.  The softmax denominator rides
+// the matrix cores too: lacc = ones . P^T accumulates sum_k p~ (the bf16-rounded p that also multiplies V) next to O^T.
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
 __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
                                              const bf16x8_t (&qf)[HD / 32], const char* tabq, int regq, int vq, int lane, float& m,
-                                             float& l, f32x4_t (&oacc)[HD / 16]) {
+                                             f32x4_t& lacc, f32x4_t (&oacc)[HD / 16], const bf16x8_t& ones) {
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT];
+    int ki[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
+        ki[t][0] = inf.x; ki[t][1] = inf.y; ki[t][2] = inf.z; ki[t][3] = inf.w;
+        s[t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq);
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks)
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8), qf[ks], s[t], 0, 0, 0);
     }
-    float sv[NT][4];
     float bm = NEG_BIG;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
-        const int ki[4] = {inf.x, inf.y, inf.z, inf.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sv[t][r] = am_fix<MODE, MASK, TAIL>(s[t][r], ki[r], tabq, regq, vq);
-            bm = fmaxf(bm, sv[t][r]);
-        }
-    }
-    bm = max4g(bm);
-    const float mn = fmaxf(m, bm);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    float ps = 0.f;
-    bf16x8_t pb[NT / 2];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(sv[t][r] - mn);
-            ps += p;
-            pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+            if (MODE != 0 || MASK || TAIL) s[t][r] = am_mask<MODE, MASK, TAIL>(s[t][r], ki[t][r], regq, vq);
+            bm = fmaxf(bm, s[t][r]);
         }
-    l = l * alpha + ps;
+    bm = max4g(bm);
+    const float mn = fmaxf(m, bm);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    bf16x8_t pb[NT / 2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[t >> 1][(t & 1) * 4 + r] = (bf16)__builtin_amdgcn_exp2f(s[t][r] - mn);
     m = mn;
+    lacc *= alpha;
+#pragma unroll
+    for (int pr = 0; pr < NT / 2; ++pr) lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[pr], lacc, 0, 0, 0);
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d) {
         oacc[d] *= alpha;
@@ -245,21 +260,26 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     float tau = 1.f;
     if (MODE == 0) {
         const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
-        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
-        C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
+        // stored REVERSED: entry (bq - ok) of the table sits at word T2-1-bq + ok, so the entries of consecutive keys ascend
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)(T2 - 1 - i) * g.H + h] * LOG2E;
+        C0 = T2 - 1 - ((g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1));
         tau = __expf(fminf(logit_scale[h], LN100));
     }
     __syncthreads();
 
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;          // keys covered by pad-free 64-key blocks
+    const bool g4 = MODE == 0 && (g.ws & 3) == 0; // four consecutive window positions share a row: adjacent bias-table words
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
     for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
         const int nq = qt * 16 + fc;
         const bool qok = nq < g.N;
         const int nqc = qok ? nq : g.N - 1;
         const int64_t tq = am_token(g, b, w, nqc);
         const int qinf = am_info(g, valid, b, w, nqc);
-        const char* tabq = (const char*)tab + 4 * ((qinf & 0xffff) + C0);
+        const char* tabq = (const char*)tab + 4 * (C0 - (qinf & 0xffff));
         const int regq = (qinf >> 16) & 0xff, vq = qinf;
         bf16x8_t qf[HD / 32];
         {
@@ -279,14 +299,20 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)(f[ks][e] * sc);
         }
-        float m = -INFINITY, l = 0.f;
+        float m = -INFINITY;
+        f32x4_t lacc = {0.f, 0.f, 0.f, 0.f};
         f32x4_t oacc[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
-        for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
-        for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, l, oacc);
-        l = sum4g(l);
+        if (g4) {
+            for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
+            for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
+        } else {
+            for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
+            for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
+        }
+        const float l = lacc[0];             // every row of ones . P^T is the same sum over ALL keys: no cross-lane reduce
         if (qok) {
             const float inv = 1.0f / l;
 #pragma unroll
@@ -321,17 +347,20 @@ __global__ __launch_bounds__(256) void attn_delta_k(const bf16* __restrict__ out
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
 // one block of NT key tiles: dS^T = P^T o (dP^T - delta), dQ^T += K^T . dS^T   (scores in log2 units, gradients in natural units)
-template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
 __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
                                             const bf16x8_t (&qf)[HD / 32], const bf16x8_t (&dof)[HD / 32], const char* tabq, int regq, int vq,
-                                            float L2q, float Dq, int lane, f32x4_t (&dq)[HD / 16]) {
+                                            float L2q, const f32x4_t& negD, int lane, f32x4_t (&dq)[HD / 16]) {
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
+    int ki[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dp[t] = s[t];
+        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
+        ki[t][0] = inf.x; ki[t][1] = inf.y; ki[t][2] = inf.z; ki[t][3] = inf.w;
+        s[t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq);       // bias and -delta are accumulator inits, not VALU ops
+        dp[t] = negD;
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             const int o = (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
@@ -341,16 +370,13 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
     }
     bf16x8_t dsb[NT / 2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
-        const int ki[4] = {inf.x, inf.y, inf.z, inf.w};
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sv = am_fix<MODE, MASK, TAIL>(s[t][r], ki[r], tabq, regq, vq);      // padding keys -> NEG_BIG -> p = 0
-            const float ds = __builtin_amdgcn_exp2f(sv - L2q) * (dp[t][r] - Dq);
-            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)ds;
+            float sv = s[t][r];
+            if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, ki[t][r], regq, vq);      // padding keys -> NEG_BIG -> p = 0
+            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(__builtin_amdgcn_exp2f(sv - L2q) * dp[t][r]);
         }
-    }
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d)
 #pragma unroll
@@ -391,8 +417,8 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     int C0 = 0;
     float tau = 1.f;
     if (MODE == 0) {
-        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
-        C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
+        for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)(T2 - 1 - i) * g.H + h] * LOG2E;     // reversed, as in the forward
+        C0 = T2 - 1 - ((g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1));
         tau = __expf(fminf(logit_scale[h], LN100));
     }
     __syncthreads();
@@ -400,13 +426,14 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     float dtau_part = 0.f;
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
+    const bool g4 = MODE == 0 && (g.ws & 3) == 0;
     for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
         const int nq = qt * 16 + fc;
         const bool qok = nq < g.N;
         const int nqc = qok ? nq : g.N - 1;
         const int64_t tq = am_token(g, b, w, nqc);
         const int qinf = am_info(g, valid, b, w, nqc);
-        const char* tabq = (const char*)tab + 4 * ((qinf & 0xffff) + C0);
+        const char* tabq = (const char*)tab + 4 * (C0 - (qinf & 0xffff));
         const int regq = (qinf >> 16) & 0xff, vq = qinf;
         bf16x8_t qf[HD / 32], dof[HD / 32];
         {
@@ -434,12 +461,18 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         }
         const float L2q = lse[lse0 + nqc] * LOG2E;
         const float Dq = qok ? delta[tq * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
+        const f32x4_t negD = {-Dq, -Dq, -Dq, -Dq};
         f32x4_t dq[HD / 16];
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
-        for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
-        for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, Dq, lane, dq);
+        if (g4) {
+            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
+            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
+        } else {
+            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, false>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
+            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
+        }
         // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
         if (MODE == 0) {
             float qh[HD / 16][4];
@@ -696,21 +729,8 @@ __global__ __launch_bounds__(256) void attn_dbias_reduce_k(const float* __restri
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // per-query info word Qi: MODE 0: 4*(iy*(2w-1)+ix + C0) | region << 16 (| AM_PAD); MODE 1: valid (| AM_PAD).  tabk = (char*)tab - 4*bk.
-template <int MODE, bool MASK, bool TAIL>
-__device__ __forceinline__ float am_fix_k(float s, int qi, const char* tabk, int regk, int vk) {
-    float v;
-    if (MODE == 0) {
-        const int off = (MASK || TAIL) ? (qi & 0xffff) : qi;
-        v = s + *(const float*)(tabk + off);
-        if (MASK) v = (((qi >> 16) & 0xff) != regk) ? v - 100.0f * LOG2E : v;
-    } else {
-        v = (vk & qi & 1) ? s : s - 10000.0f * LOG2E;
-    }
-    if (TAIL) v = (qi & AM_PAD) ? NEG_BIG : v;
-    return v;
-}
-
-template <int HD, int MODE, bool MASK, bool TAIL, int NT>
+// Qd holds MINUS delta: it is the initial accumulator of the dP = dO.V^T product, as the bias is of S = Q~.K^T.
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
 __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const bf16* __restrict__ Ds, const int* __restrict__ Qi,
                                              const float* __restrict__ Ql, const float* __restrict__ Qd, int qb, const bf16x8_t (&kf)[HD / 32],
                                              const bf16x8_t (&vf)[HD / 32], const char* tabk, int regk, int vk, int lane,
@@ -718,10 +738,13 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
+    int qi[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dp[t] = s[t];
+        const int4 inf = *(const int4*)(Qi + qb + 16 * t + 4 * fg);
+        qi[t][0] = inf.x; qi[t][1] = inf.y; qi[t][2] = inf.z; qi[t][3] = inf.w;
+        s[t] = am_bias4<MODE, MASK, TAIL, G4>(qi[t], tabk);
+        dp[t] = *(const f32x4_t*)(Qd + qb + 16 * t + 4 * fg);
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             const int o = (qb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
@@ -732,18 +755,15 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
     bf16x8_t pb[NT / 2], dsb[NT / 2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int4 inf = *(const int4*)(Qi + qb + 16 * t + 4 * fg);
         const float4 l4 = *(const float4*)(Ql + qb + 16 * t + 4 * fg);
-        const float4 d4 = *(const float4*)(Qd + qb + 16 * t + 4 * fg);
-        const int qi[4] = {inf.x, inf.y, inf.z, inf.w};
         const float L[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float D[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sv = am_fix_k<MODE, MASK, TAIL>(s[t][r], qi[r], tabk, regk, vk);
+            float sv = s[t][r];
+            if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, qi[t][r], regk, vk);
             const float p = __builtin_amdgcn_exp2f(sv - L[r]);                 // padding queries -> NEG_BIG -> 0
             pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
-            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * (dp[t][r] - D[r]));
+            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * dp[t][r]);
         }
     }
 #pragma unroll
@@ -796,10 +816,11 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
             D = delta[am_token(g, b, w, i) * g.H + h];
         }
         Ql[i] = L;
-        Qd[i] = D;
+        Qd[i] = -D;
     }
     __syncthreads();
 
+    const bool g4 = MODE == 0 && (g.ws & 3) == 0;
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
     for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * (blockDim.x >> 6)) {
@@ -833,8 +854,13 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
         int qb = 0;
-        for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
-        for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        if (g4) {
+            for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+            for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        } else {
+            for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+            for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+        }
         // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc; dk was accumulated against q~ * log2(e)
         if (kok) {
 #pragma unroll
