@@ -7,10 +7,12 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = forward + cross-entropy + backward + (N>1: flat-buffer RCCL all-reduce) + global-norm clip + fused AdamW +
-LR update over one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task prompt)
-with two extra objects: ``roofline`` for the dominant kernel family (timed live with HIP events on the launch
-stream, in one instrumented step outside the timed region) and ``cpu_baseline`` (the oracle port timed on the host
-cores on a bounded sample; N=1 only).
+LR update over one synthetic batch already resident in HBM (token ids with their host-side non-pad counts, as the data
+loader hands them over: the text encoder runs pad-free).  Rank 0 prints ONE JSON line (contract in the task prompt) with
+extra objects: ``roofline`` for the dominant kernel family (timed live with HIP events on the launch stream, in one
+instrumented single-stream step outside the timed region), ``cpu_baseline`` (the oracle port timed on the host cores,
+BASELINE.md section 4 protocol; N=1 only) and ``inference`` (BASELINE configs[3]: the eval forward at batch 256 captured in a
+hipGraph and replayed; N=1 only).  ``--mode infer --batch 256`` prints that leg as the headline line instead.
 """
 import argparse
 import json
@@ -38,9 +40,14 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cfg", default=CFG)
     ap.add_argument("--opts", nargs="+", default=None)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train: BASELINE configs[1]/[2] (the headline); infer: configs[3], hipGraph-captured eval forward (use --batch 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="functions in the CPU-baseline sample")
+    ap.add_argument("--no-infer", action="store_true", help="train mode: skip the extra batch-256 hipGraph inference leg")
+    ap.add_argument("--infer-batch", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="functions per step of the CPU baseline (BASELINE.md section 4: batch 4)")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="stop the CPU baseline's timed runs once this much time is spent")
     return ap.parse_args()
 
 
@@ -89,7 +96,7 @@ def main():
     device = torch.device(f"cuda:{local}")
     from mvuld_amd import hip, ops
     hip.LIB.load()
-    from mvuld_amd.distributed import GradAllReducer, broadcast_parameters, init_distributed, world_size
+    from mvuld_amd.distributed import attach_gradient_exchange, broadcast_parameters, init_distributed, world_size
     import torch.distributed as dist
     if world > 1:
         init_distributed(local)
@@ -97,17 +104,19 @@ def main():
     from mvuld_amd.models.GraphModel import cross_entropy
 
     config, model, opt, sched, batch = build(args, device, rank)
+    if args.mode == "infer":
+        out = infer_leg(args, config, model, device, world_size(), steps=args.steps, warmup=args.warmup)
+        out["cpu_baseline"] = None
+        if rank == 0:
+            print(json.dumps(out))
+        if world_size() > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     store = model._mv_store
     broadcast_parameters(store.flat)
     store.refresh_working_copy()
-    store.grad_scale = 1.0 / world_size()
-    reducer = GradAllReducer(store.grad)
-    if world_size() > 1:
-        # Swin gradients go out stage by stage, as each stage's backward completes (stage 3 and 2 hold 95 % of them and
-        # finish early); patch_embed / norm / whatever else is left goes with finish()
-        for _i in range(4):
-            ops.on_backward_done(f"swin.layers.{_i}", lambda _i=_i: reducer.launch_ranges(store.segment(f"swin.layers.{_i}.")))
-        ops.on_backward_done("unixcoder", lambda: reducer.launch_ranges(store.segment("unixcoder.")))
+    reducer = attach_gradient_exchange(store)        # N > 1: per-stage / per-encoder all-reduce launches from inside backward
     g, images, ids, labels, lens = batch
     it = [0]
 
@@ -147,6 +156,16 @@ def main():
     value = n_fn / dt
     ms_per_step = dt / args.steps * 1e3
 
+    # host cost of enqueueing one step, with the two-steps-in-flight throttle off (3 steps queue up behind the GPU)
+    fence()
+    model.max_steps_in_flight = 0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    host_unthrottled_ms = (time.perf_counter() - t0) / 3 * 1e3
+    model.max_steps_in_flight = 2
+    fence()
+
     roofline = None
     if not args.no_kernel_timing:
         hip.TIMING.enable()
@@ -155,6 +174,16 @@ def main():
         fam = hip.TIMING.summary()
         hip.TIMING.disable()
         roofline = make_roofline(fam, ms_per_step)
+
+    inference = None
+    if not args.no_infer and world_size() == 1:
+        try:
+            inf = infer_leg(args, config, model, device, 1)
+            inference = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup")}
+            inference.update({"batch_per_gpu": args.infer_batch, "graph_replay_equals_eager": inf["config"]["graph_replay_equals_eager"],
+                              "frac_of_dense_bf16_peak": inf["config"]["frac_of_dense_bf16_peak"]})
+        except Exception as e:                      # the headline must still print
+            inference = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world_size() == 1 and not args.no_cpu_baseline:
@@ -172,13 +201,81 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": round(fl * args.batch / 1e12, 2),
                        "achieved_tflops_per_gpu": round(fl * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
                        "frac_of_dense_bf16_peak": round(fl * args.batch / (ms_per_step * 1e-3) / PEAK_BF16, 4),
-                       "host_enqueue_ms_per_step": round(host_ms, 2), "final_loss": round(loss_val, 5)},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "host_loop_ms_per_step": round(host_ms, 2), "host_enqueue_ms_per_step": round(host_unthrottled_ms, 2),
+                       "text_tokens_nonpad_frac": round(float(lens.sum()) / ids.numel(), 4), "final_loss": round(loss_val, 5)},
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference,
         }
         print(json.dumps(out))
     if world_size() > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def infer_leg(args, config, model, device, world, steps=5, warmup=2):
+    """BASELINE configs[3]: inference-only fused forward at `infer_batch` functions per GPU, captured ONCE in a hipGraph (both
+    streams, every launch through the C ABI, pad-free text encoder from a precomputed packing plan) and replayed.
+    Returns the dict bench.py prints (mode infer) or embeds under "inference" (mode train)."""
+    from mvuld_amd import hip
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.models.unixcoder import RobertaModel
+    B = args.infer_batch
+    f = config.FUSED
+    rank = int(os.environ.get("RANK", 0))
+    idx = [10_000 + rank * B + i for i in range(B)]
+    g, images, ids, _ = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g.index()
+    plan = RobertaModel.pack_plan((ids != 1).sum(1), device, ids.shape[1])      # device-resident cu_seqlens: no host work inside the graph
+    g, images, ids = g.to(device), images.to(device), ids.to(device)
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            eager = model(g, images, ids, seq_lens=plan).float().clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(g, images, ids, seq_lens=plan)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(g, images, ids, seq_lens=plan)
+        for _ in range(warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        same = bool(torch.equal(out.float(), eager))
+        roofline = None
+        if not args.no_kernel_timing:
+            hip.TIMING.enable()
+            model(g, images, ids, seq_lens=plan)
+            torch.cuda.synchronize()
+            fam = hip.TIMING.summary()
+            hip.TIMING.disable()
+            roofline = make_roofline(fam, dt / steps * 1e3)
+        del graph, out
+    model.train(was_training)
+    fl = algorithmic_flops_per_function(config) / 3.0                           # forward only
+    ms = dt / steps * 1e3
+    return {"metric": "functions/sec (inference, hipGraph-captured fused forward)", "value": round(B * world * steps / dt, 3), "unit": "functions/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "fused MVulD eval forward (BASELINE configs[3]): SwinV2-base 448x448 + UniXcoder 12x768 @512 tokens (pad-free) + "
+                                   "GAT/Rs_GCN head, one hipGraph replay per step", "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"replicas x{world}", "graph_replay_equals_eager": same,
+                       "algorithmic_tflop_per_step_per_gpu": round(fl * B / 1e12, 2),
+                       "frac_of_dense_bf16_peak": round(fl * B / (ms * 1e-3) / PEAK_BF16, 4)},
+            "roofline": roofline}
 
 
 def make_roofline(fam, ms_per_step):
@@ -194,7 +291,7 @@ def make_roofline(fam, ms_per_step):
     else:
         ach = d["bytes"] / sec / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4)}
-    r.update({"traffic": measured_traffic(name), "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_hbm_traffic.csv)",
+    r.update({"traffic": measured_traffic(name), "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_hbm_traffic.csv)",
               "kernel": name, "launches_per_step": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["n"]), 2),
               "kernel_ms_per_step": round(d["ms"], 3), "step_ms": round(ms_per_step, 3), "top_kernels_ms": top})
     return r
@@ -203,7 +300,7 @@ def make_roofline(fam, ms_per_step):
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (separate --pmc passes,
     FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profile.py).  None when the summary has no such row."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.csv")
     if not os.path.exists(path):
         return None
     import csv
@@ -213,13 +310,39 @@ def measured_traffic(kernel):
     return None
 
 
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or 0
+    except Exception:
+        phys = 0
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return model, phys, avail
+
+
 def cpu_baseline(config, args):
-    """The oracle port (plain PyTorch fp32) on the host cores: fused forward + CE + backward + AdamW on `cpu_sample`
-    functions of the same workload.  A reported baseline, not the target."""
+    """the oracle port (plain PyTorch fp32 -- oracle/fused_ref.py; test infrastructure, imported here only as
+    the reported baseline) on the GPU box's host cores: one fused train step (forward + CE + backward + clip + AdamW) on a batch of
+    `cpu_sample` functions of the same synthetic workload, 2 warm-ups, median of up to 5 timed runs (fewer if `cpu_budget_s` runs
+    out), torch threads = physical cores available to this process.  A reported baseline, not the target."""
     from oracle import fused_ref, swin_ref, roberta_ref
     from mvuld_amd import synth
     from mvuld_amd.data import synthetic
     n = args.cpu_sample
+    model_name, phys, avail = cpu_info()
+    cores = max(1, min(phys, avail) if phys else avail)
+    torch.set_num_threads(cores)
     sw = config.MODEL.SWINV2
     scfg = swin_ref.SwinCfg(img_size=config.DATA.IMG_SIZE, embed_dim=sw.EMBED_DIM, depths=list(sw.DEPTHS), num_heads=list(sw.NUM_HEADS),
                             window_size=sw.WINDOW_SIZE, pretrained_window_sizes=list(sw.PRETRAINED_WINDOW_SIZES))
@@ -232,16 +355,28 @@ def cpu_baseline(config, args):
     g, images, ids, labels = synthetic.make_batch(list(range(n)), config.DATA.IMG_SIZE, config.FUSED.SEQ_LEN, t.VOCAB,
                                                   config.FUSED.NODES_LO, config.FUSED.NODES_HI)
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.005)
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    loss, _ = fused_ref.fused_loss(sd, images, ids, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"],
-                                   labels, scfg, rcfg, training=True)
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(params, 5.0)
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "functions/s", "cores": cores, "kind": "port",
-            "sample": f"{n} functions, one fused fwd+CE+bwd+clip+AdamW step of the oracle (PyTorch fp32 CPU), {dt:.1f} s"}
+
+    def one():
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, _ = fused_ref.fused_loss(sd, images, ids, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"],
+                                       labels, scfg, rcfg, training=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        return time.perf_counter() - t0
+
+    t_all = time.perf_counter()
+    warm = [one() for _ in range(2)]
+    runs = []
+    while len(runs) < 5 and (not runs or time.perf_counter() - t_all < args.cpu_budget_s):
+        runs.append(one())
+    runs.sort()
+    med = runs[len(runs) // 2]
+    return {"value": round(n / med, 4), "unit": "functions/s", "cores": cores, "kind": "port",
+            "cpu_model": model_name, "physical_cores": phys, "threads_used": cores,
+            "sample": f"batch {n}, fused fwd+CE+bwd+clip+AdamW step of the oracle (PyTorch fp32 CPU): 2 warm-ups ({warm[0]:.1f}, {warm[1]:.1f} s), "
+                      f"median of {len(runs)} timed runs = {med:.2f} s/step"}
 
 
 if __name__ == "__main__":

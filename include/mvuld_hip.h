@@ -173,6 +173,10 @@ int mvuld_embed_fwd(const int64_t* ids, const int* pos, const float* word, const
 int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* dword, float* dposw, int64_t ntok, int H,
                     int vocab, int maxpos, int dtype, mvuld_stream_t stream);
 
+/* y[i] = x[i] * s[0], s one fp32 on the device: upstream gradient of the scalar loss applied to dlogits (autograd of
+ * CrossEntropyLoss when the loss is scaled or summed with other terms, main_bigvul.py:331-333) */
+int mvuld_scale_by_dev(const float* x, const float* s, float* y, int64_t n, mvuld_stream_t stream);
+
 /* Packed (pad-free) token sequences.  The reference pads every function / source line to 512 tokens and masks the pad keys
  * (unixcoder.py:33-38,56-68; data_list.py:293-299); pad rows never reach a result (masked mean, :37), so the text encoder may
  * run on the non-pad tokens only.  cu [B+1] (int32, device): cu[b] .. cu[b+1]-1 are the packed rows of sequence b (exclusive scan

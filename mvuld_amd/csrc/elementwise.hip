@@ -709,3 +709,16 @@ extern "C" int mvuld_rows_map(const void* src, const int* map, void* dst, int64_
     MV_LAUNCH_CHECK("rows_map");
     return 0;
 }
+
+// y[i] = x[i] * s[0]  (s = one fp32 on the device): the upstream gradient of the scalar loss applied to dlogits without a host
+// round trip (autograd of CrossEntropyLoss under loss * k / a sum of losses: main_bigvul.py:331-333)
+__global__ void scale_by_dev_k(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * s[0];
+}
+extern "C" int mvuld_scale_by_dev(const float* x, const float* s, float* y, int64_t n, hipStream_t stream) {
+    MV_CHECK_ARG(x && s && y && n > 0, "scale_by_dev: bad args");
+    hipLaunchKernelGGL(scale_by_dev_k, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, x, s, y, n);
+    MV_LAUNCH_CHECK("scale_by_dev");
+    return 0;
+}

@@ -47,9 +47,36 @@ def barrier():
         dist.barrier()
 
 
+def gather_cat(t: torch.Tensor) -> torch.Tensor:
+    """Concatenation over ranks of equally shaped tensors (validation outputs: every rank then derives the same metrics)."""
+    if world_size() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(world_size())]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat(parts, 0)
+
+
 def broadcast_parameters(flat: torch.Tensor, src=0):
     if world_size() > 1:
         dist.broadcast(flat, src)
+
+
+def attach_gradient_exchange(store, max_bucket_elems=64 * 1024 * 1024):
+    """The data-parallel wiring of one fused training step (what DDP's reducer hooks are to the reference, main_bigvul.py:162-164),
+    shared by bench.py and main_bigvul.py: a GradAllReducer over the store's flat gradient buffer whose per-range launches fire from
+    inside backward -- each Swin stage when its first block has launched its last backward kernel (stage 3 and 2 hold 95 % of the
+    Swin gradients and finish early), the text encoder from its first op; everything else goes out with `reducer.finish()`.
+    Also sets the 1/world factor the clip coefficient folds in.  Returns the reducer (call .finish() after backward)."""
+    from . import ops
+    reducer = GradAllReducer(store.grad, max_bucket_elems)
+    store.grad_scale = 1.0 / world_size()
+    tags = [f"swin.layers.{i}" for i in range(4)] + ["unixcoder"]
+    for tag in tags:
+        if world_size() > 1:
+            ops.on_backward_done(tag, lambda tag=tag: reducer.launch_ranges(store.segment(tag + ".")), key="grad-exchange")
+        else:
+            ops.on_backward_done(tag, None, key="grad-exchange")
+    return reducer
 
 
 class GradAllReducer:
@@ -85,6 +112,7 @@ class GradAllReducer:
         if self.g.is_cuda:
             from . import ops
             ops.join_wgrad_stream()           # gradients still being accumulated on the weight-gradient stream
+            ops.join_grad_streams()           # ... or on any other stream of the step, whatever order autograd replayed them in
         covered = sorted(self.done)
         pos = 0
         for a, b in covered + [(self.g.numel(), self.g.numel())]:

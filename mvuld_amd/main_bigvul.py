@@ -34,7 +34,8 @@ if os.path.dirname(_HERE) not in sys.path:
 
 from mvuld_amd.config import get_config                                   # noqa: E402
 from mvuld_amd.data.bigvul_dataset import bigvul_loader_graph              # noqa: E402
-from mvuld_amd.distributed import GradAllReducer, broadcast_parameters, init_distributed, world_size  # noqa: E402
+from mvuld_amd.distributed import (GradAllReducer, attach_gradient_exchange, barrier, broadcast_parameters, get_rank, init_distributed,  # noqa: E402
+                                   world_size)
 from mvuld_amd.logger import create_logger                                 # noqa: E402
 from mvuld_amd.lr_scheduler import build_scheduler                         # noqa: E402
 from mvuld_amd.metrics import AverageMeter, accuracy, average_precision, binary_prf  # noqa: E402
@@ -117,15 +118,11 @@ def myMain(config, args, device):
     store = model._mv_store
     broadcast_parameters(store.flat)                     # DDP construction: rank 0's parameters everywhere
     store.refresh_working_copy()
-    reducer = GradAllReducer(store.grad)
-    if config.FUSED.ENABLE and world_size() > 1 and config.TRAIN.ACCUMULATION_STEPS == 1:
-        from mvuld_amd import ops
-        # Swin gradients go out stage by stage, as each stage's backward completes (stage 3 and 2 hold 95 % of them and
-        # finish early); patch_embed / norm / whatever else is left goes with finish()
-        for _i in range(4):
-            ops.on_backward_done(f"swin.layers.{_i}", lambda _i=_i: reducer.launch_ranges(store.segment(f"swin.layers.{_i}.")))
-        ops.on_backward_done("unixcoder", lambda: reducer.launch_ranges(store.segment("unixcoder.")))
-    store.grad_scale = 1.0 / world_size()
+    if config.FUSED.ENABLE and config.TRAIN.ACCUMULATION_STEPS == 1:
+        reducer = attach_gradient_exchange(store)        # exchange launched range by range from inside backward
+    else:
+        reducer = GradAllReducer(store.grad)             # head-only model / gradient accumulation: one exchange after backward
+        store.grad_scale = 1.0 / world_size()
     loss_scaler = NativeScalerWithGradNormCount(grad_sync=reducer.finish)
     n_iter = len(data_loader_train) // max(1, config.TRAIN.ACCUMULATION_STEPS)
     lr_scheduler = build_scheduler(config, optimizer, max(1, n_iter))
@@ -166,8 +163,10 @@ def myMain(config, args, device):
                 output_dir = os.path.join(config.MULTI_OUTPUT, 'checkpoint-best-f1')
                 os.makedirs(output_dir, exist_ok=True)
                 max_accuracy = max(max_accuracy, acc1)
-                save_bestf1_checkpoint(config, epoch, model_without_ddp, max_accuracy, optimizer, lr_scheduler, loss_scaler, logger)
-                torch.save(model_without_ddp.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
+                if get_rank() == 0:            # one writer; the others wait so that nobody races ahead of a half-written file
+                    save_bestf1_checkpoint(config, epoch, model_without_ddp, max_accuracy, optimizer, lr_scheduler, loss_scaler, logger)
+                    torch.save(model_without_ddp.state_dict(), os.path.join(output_dir, "pytorch_model.bin"))
+                barrier()
             else:
                 not_f1_inc_cnt += 1
                 logger.info("f1 does not increase for %d epochs", not_f1_inc_cnt)
@@ -252,8 +251,11 @@ def validate(config, data_loader, model, device):
         if idx % config.PRINT_FREQ == 0:
             logger.info(f'Test: [{idx}/{len(data_loader)}]\tTime {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
                         f'Loss {loss_meter.val:.4f} ({loss_meter.avg:.4f})\tAcc@1 {acc1_meter.val:.3f} ({acc1_meter.avg:.3f})')
-    all_prob = torch.cat(probs_all, 0).cpu().numpy()
-    all_target = torch.cat(targets_all, 0).cpu().numpy()
+    # every rank evaluates its DistributedSampler shard; P / R / F1 / PR-AUC are taken over ALL shards so that every rank reaches the
+    # same "best f1" / early-stop decision (ranks that disagree would leave the others blocked in the next gradient all-reduce)
+    from mvuld_amd.distributed import gather_cat
+    all_prob = gather_cat(torch.cat(probs_all, 0)).cpu().numpy()
+    all_target = gather_cat(torch.cat(targets_all, 0)).cpu().numpy()
     all_predict = all_prob[:, 1] > 0.5                                   # probability threshold (:447)
     P, R, F1Score, TP, FN = binary_prf(all_target, all_predict)
     logger.info(f' * TP {TP:.3f} and (TP+FN) {TP + FN}')

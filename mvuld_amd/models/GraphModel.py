@@ -257,10 +257,13 @@ class _CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _dp):
-        # the upstream factor is taken to be 1 (loss.backward()); scale through `loss_scale` instead, so that no
-        # host sync / torch arithmetic is needed here
+        # dlog was formed in forward for an upstream factor of 1; whatever autograd hands down (1 for loss.backward(), k for
+        # (k * loss).backward(), ...) is applied on the device: no host sync, no torch arithmetic
         (dlog,) = ctx.saved_tensors
-        return dlog, None, None
+        out = torch.empty_like(dlog)
+        dloss = dloss.to(torch.float32).contiguous()
+        call("scale_by_dev", ptr(dlog), ptr(dloss), ptr(out), dlog.numel())
+        return out, None, None
 
 
 def cross_entropy(logits, target, loss_scale=1.0):

@@ -29,6 +29,7 @@ class FusedMVulD(nn.Module):
         self._side = None
         self._wg = None
         self._inflight = []
+        self.max_steps_in_flight = 2          # 0 = do not throttle the host (bench.py's enqueue-cost measurement)
         for n, p in self.head.named_parameters():
             if n.startswith(self.head.unused_parameter_prefixes):
                 p.requires_grad_(False)
@@ -63,17 +64,19 @@ class FusedMVulD(nn.Module):
             # Bound how far the host may run ahead of the GPU: tensors handed to another stream (record_stream) cannot be reused
             # until that stream has passed them, so an unthrottled host (24 ms of enqueue per 66 ms step) keeps a few hundred MB
             # more alive for every step it is ahead.  Two steps in flight lose nothing.
-            if not torch.cuda.is_current_stream_capturing():
+            if not torch.cuda.is_current_stream_capturing() and self.max_steps_in_flight > 0:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 self._inflight.append(ev)
-                if len(self._inflight) > 2:
+                while len(self._inflight) > self.max_steps_in_flight:
                     self._inflight.pop(0).synchronize()
             if self._side is None:
                 self._side = torch.cuda.Stream(device=images.device)
             side = self._side
             if self._wg is None:
                 self._wg = torch.cuda.Stream(device=images.device)
+            ops.register_grad_stream(side)
+            ops.register_grad_stream(self._wg)
             # third stream: the image encoder's weight gradients (nothing in backward depends on them); joined into the main
             # stream when the encoder's first op has finished its backward (ops.fire_backward_done("swin"))
             use_wg = torch.is_grad_enabled() and self.training and os.environ.get("MVULD_WGRAD_STREAM", "1") != "0"

@@ -232,6 +232,27 @@ def _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk):
          ptr(ws), ws.numel() if ws is not None else 0)
 
 
+# Streams other than the caller's that accumulate parameter gradients during a step (the fused model's side and weight-gradient
+# streams).  Gradients are written by raw atomics into the flat store, invisible to autograd's stream bookkeeping, so everything
+# that READS the gradient buffer (all-reduce launch, norm, AdamW) first makes its stream wait for all of them -- cheap, and
+# independent of the order in which autograd happened to replay the branches.
+GRAD_STREAMS = []
+
+
+def register_grad_stream(stream):
+    if all(s.cuda_stream != stream.cuda_stream for s in GRAD_STREAMS):
+        GRAD_STREAMS.append(stream)
+
+
+def join_grad_streams():
+    cur = torch.cuda.current_stream()
+    for s in GRAD_STREAMS:
+        if s.cuda_stream != cur.cuda_stream:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            cur.wait_event(ev)
+
+
 def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  and  db[N] += colsum(dy), into the parameters' fp32 .grad buffers.
     bias_out: an fp32 [N] buffer to accumulate colsum(dy) into instead of b_param.grad.  Returns the stream the gradient

@@ -102,6 +102,7 @@ class ParamStore:
         if self.flat.is_cuda:
             ops.join_wgrad_stream()           # weight gradients issued on the side stream must have landed
             ops.WGRAD_STREAM[0] = None
+            ops.join_grad_streams()           # ... and so must every other stream that accumulated gradients this step
         self._sumsq.zero_()
         call("sumsq", ptr(self.grad), self.total, ptr(self._sumsq_partials), ptr(self._sumsq))
         call("clip_coef", ptr(self._sumsq), float(max_norm) if max_norm else 0.0, float(grad_scale), ptr(self.norm))
@@ -126,7 +127,12 @@ class FusedAdamW(torch.optim.Optimizer):
         if st.flat.is_cuda:
             ops.join_wgrad_stream()
             ops.WGRAD_STREAM[0] = None
+            ops.join_grad_streams()
         self._step += 1
+        if not self._clipped and st.grad_scale != 1.0:
+            # step() without clip_grad_norm_() first: the all-reduced buffer holds SUMS over ranks, the 1/world factor still has to
+            # reach the kernel -- through the same coefficient, with clipping off
+            self.clip_grad_norm_(0.0)
         coef = st.norm if self._clipped else None
         for (a, b), grp in zip(st.group_ranges, self.param_groups):
             if b <= a:

@@ -14,8 +14,8 @@ additive term (1 - m) * -10000 (no causal mask even with is_decoder=True, which
 unixcoder.py:109 sets).  Position ids: cumsum(ids != pad) * (ids != pad) + pad.
 Post-LN blocks, GELU(erf), LayerNorm eps from config (1e-5), scale 1/sqrt(64).
 Dropout is identity (eval or p = 0).  **Parity unpinned** by any reference test;
-tests/test_oracle_cpu.py cross-checks this file against the installed
-transformers RobertaModel driven with the equivalent 4-D additive mask.
+tests/test_cpu_oracle_and_host.py::test_oracle_roberta_matches_golden checks this file against fixtures generated
+(tests/golden/make_golden.py) from the installed transformers RobertaModel driven with the equivalent 4-D additive mask.
 """
 import math
 from dataclasses import dataclass

@@ -62,3 +62,62 @@ def test_flat_gradient_allreduce_gloo_world2(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def _worker_wiring(rank, world, port, out):
+    """bench.py / main_bigvul.py's data-parallel wiring end to end on a real (CPU) ParamStore under gloo: parameter broadcast,
+    attach_gradient_exchange's hooks fired in the order backward fires them, finish(), 1/world factor -- everything but the kernels
+    and the backend string."""
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from mvuld_amd import ops
+    from mvuld_amd.config import get_config
+    from mvuld_amd.distributed import attach_gradient_exchange, broadcast_parameters, gather_cat, init_distributed, world_size
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.optimizer import build_optimizer
+    init_distributed(backend="gloo")
+    cfg = os.path.join(root, "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "fp32"], batch_size=2, local_rank=0))
+    torch.manual_seed(50 + rank)
+    model = build_fused_model(config)                    # CPU: parameters and the flat store only, no kernel runs
+    build_optimizer(config, model)
+    store = model._mv_store
+    broadcast_parameters(store.flat)
+    ref = [torch.zeros(store.total) for _ in range(world)]
+    dist.all_gather(ref, store.flat.detach())
+    assert torch.equal(ref[0], ref[1])
+    reducer = attach_gradient_exchange(store, max_bucket_elems=1 << 18)
+    assert store.grad_scale == 1.0 / world
+    launched = []
+    orig = reducer.launch_ranges
+    reducer.launch_ranges = lambda ranges: (launched.append(list(ranges)), orig(ranges))[1]
+    for step in range(2):
+        store.grad.copy_(torch.arange(store.total, dtype=torch.float32) % 97 * (rank + 1 + step))
+        # the order autograd replays the fused model: graph branch (no tag), Swin stage 3 .. 0, patch embedding ("swin"), text encoder
+        for tag in ("swin.layers.3", "swin.layers.2", "swin.layers.1", "swin.layers.0", "swin", "unixcoder"):
+            ops.fire_backward_done(tag)
+        reducer.finish()
+        want = torch.arange(store.total, dtype=torch.float32) % 97 * sum(r + 1 + step for r in range(world))
+        assert torch.equal(store.grad, want), float((store.grad - want).abs().max())
+    assert len(launched) == 10 and all(len(r) >= 1 for r in launched)          # 5 tagged ranges per step went out from "inside backward"
+    covered = sum(b - a for r in launched[:5] for a, b in r)
+    enc = sum(p.numel() for n, p in model.named_parameters() if p.requires_grad and n.startswith(("swin.layers.", "unixcoder.")))
+    assert enc <= covered <= store.total                                     # every encoder gradient left before finish()
+    # validation: per-rank shards differ, the gathered metric inputs do not
+    probs = torch.full((3, 2), float(rank))
+    allp = gather_cat(probs)
+    assert allp.shape == (3 * world, 2) and float(allp.sum()) == 6.0 * sum(range(world))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        open(out, "w").write("ok")
+
+
+def test_bench_data_parallel_wiring_gloo_world2(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_wiring, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

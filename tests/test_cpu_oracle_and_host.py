@@ -83,6 +83,35 @@ def test_oracle_gat_softmax_properties():
         assert torch.allclose(out[d], ft[inc].mean(0), atol=1e-6)
 
 
+def test_oracle_gat_matches_dense_formulation():
+    """Second, independent statement of DGL 0.8.1's GATConv (the library itself cannot be executed here: no wheel, no network): the
+    edge list becomes an edge-MULTIPLICITY matrix A[dst, src], attention a masked softmax over each destination's row in which a
+    multi-edge counts A times -- no scatter, no per-edge tensors.  Must agree with the sparse restatement oracle/head_ref.gat_conv
+    on random multigraphs with duplicate edges, duplicate self-loops and in-degree-1 nodes."""
+    from oracle import head_ref
+    gen = torch.Generator().manual_seed(3)
+    for N, E, H, O, Fin in ((7, 30, 2, 4, 5), (40, 300, 4, 8, 16), (13, 13, 3, 5, 6)):
+        src = torch.randint(0, N, (E,), generator=gen)
+        dst = torch.randint(0, N, (E,), generator=gen)
+        src = torch.cat([src, src[:5], torch.arange(N), torch.arange(3)])       # repeated edges, one self-loop per node, extra self-loops
+        dst = torch.cat([dst, dst[:5], torch.arange(N), torch.arange(3)])
+        sd = {"fc.weight": torch.randn(H * O, Fin, generator=gen), "attn_l": torch.randn(1, H, O, generator=gen),
+              "attn_r": torch.randn(1, H, O, generator=gen), "bias": torch.randn(H * O, generator=gen)}
+        x = torch.randn(N, Fin, generator=gen)
+        sparse = head_ref.gat_conv(sd, "", x, src, dst, H, O)
+        ft = (x.double() @ sd["fc.weight"].double().t()).view(N, H, O)
+        el = (ft * sd["attn_l"].double()).sum(-1)                                # [N, H] source term
+        er = (ft * sd["attn_r"].double()).sum(-1)                                # [N, H] destination term
+        A = torch.zeros(N, N, dtype=torch.float64)
+        A.index_put_((dst, src), torch.ones(src.numel(), dtype=torch.float64), accumulate=True)
+        e = torch.nn.functional.leaky_relu(er[:, None, :] + el[None, :, :], 0.2)  # [dst, src, H]
+        e = e.masked_fill((A == 0)[..., None], float("-inf"))
+        w = torch.exp(e - e.amax(1, keepdim=True)) * A[..., None]                # multiplicity-weighted
+        att = w / w.sum(1, keepdim=True)
+        dense = torch.einsum("dsh,sho->dho", att, ft) + sd["bias"].double().view(1, H, O)
+        assert torch.allclose(sparse.double(), dense, atol=1e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ C ABI surface
 def test_library_exports_every_declared_symbol():
     from mvuld_amd import hip
@@ -297,15 +326,107 @@ def test_state_dict_key_parity_with_reference_names():
                           pretrained_window_sizes=[12, 12, 12, 6])
     keys = {k for k in m.state_dict() if not k.endswith("relative_coords_table")}
     assert keys == set(swin_ref.swin_param_shapes(cfg))
-    assert sum(p.numel() for p in m.parameters()) == 86_899_724 + 2 * 1024 + 2 - 1000 * 1024 - 1000 or True
+    assert sum(p.numel() for p in m.parameters()) == 86_895_866          # SwinV2-base 448 / window 28 with a 2-class head (86.90 M)
     rc = RobertaConfigLite()
     u = MyUniXcoder(RobertaModel(rc), rc)
     keys = {k for k in u.state_dict() if not k.startswith("classifier")}
     assert keys == set(roberta_ref.roberta_param_shapes(roberta_ref.RobertaCfg()))
     h = Multi_DefectModel_new_GCN(types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2)))
     assert set(h.state_dict()) == set(head_ref.head_param_shapes(2))
-    assert sum(p.numel() for p in h.parameters()) == 19_178_738 or sum(p.numel() for p in h.parameters()) > 19_000_000
+    assert sum(p.numel() for p in h.parameters()) == 19_178_002          # the reference head's 19.178 M
     # round trip through the split q/k/v names
     sd = u.state_dict()
     assert "encoder.encoder.layer.0.attention.self.query.weight" in sd and "encoder.encoder.layer.0.attention.self.qkv_weight" not in sd
     u.load_state_dict(sd)
+
+
+def _mini_swin(num_classes=2, pws=(12, 12, 12, 6)):
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    return SwinTransformerV2(img_size=224, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=14, num_classes=num_classes,
+                             pretrained_window_sizes=list(pws))
+
+
+def test_load_pretrained_reference_layout(tmp_path):
+    """utils_multi.load_pretrained on a file laid out as the reference / upstream Swin writes it: geometry buffers present
+    (relative_position_index [N,N], attn_mask [nW,N,N], a relative_coords_table of ANOTHER pretrained window), a 1000-class head.
+    Every learnable tensor must arrive, the geometry must be ignored, the mismatched head re-initialised to zero (utils_multi.py:35-122)."""
+    import logging
+    from mvuld_amd import utils_multi as um
+    from mvuld_amd.config import get_config
+    src = _mini_swin(num_classes=1000, pws=(7, 7, 7, 7))
+    g = torch.Generator().manual_seed(5)
+    sd = {k: (torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()) for k, v in src.state_dict().items()}
+    for i, (depth, res) in enumerate(zip((2, 2, 2, 2), (56, 28, 14, 7))):
+        ws = min(14, res)
+        for j in range(depth):
+            sd[f"layers.{i}.blocks.{j}.attn.relative_position_index"] = torch.zeros(ws * ws, ws * ws, dtype=torch.long)
+            if j % 2 == 1 and res > ws:
+                sd[f"layers.{i}.blocks.{j}.attn_mask"] = torch.zeros((res // ws) ** 2, ws * ws, ws * ws)
+    f = str(tmp_path / "swin_pre.pth")
+    torch.save({"model": sd}, f)
+    cfg_file = os.path.join(ROOT, "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    cfg = get_config(types.SimpleNamespace(cfg=cfg_file, opts=["MODEL.PRETRAINED", f], batch_size=2, local_rank=0))
+    dst = _mini_swin(num_classes=2)
+    coords_before = dst.layers[0].blocks[0].attn.relative_coords_table.clone()
+    msg = um.load_pretrained(cfg, dst, logging.getLogger("t"))
+    own = dst.state_dict()
+    for k, v in sd.items():
+        if any(t in k for t in ("relative_position_index", "relative_coords_table", "attn_mask")) or k.startswith("head."):
+            continue
+        assert torch.equal(own[k], v), k
+    assert torch.equal(dst.layers[0].blocks[0].attn.relative_coords_table, coords_before)       # own geometry kept (pretrained window 12)
+    assert float(dst.head.weight.abs().max()) == 0.0 and float(dst.head.bias.abs().max()) == 0.0
+    assert not [k for k in msg.unexpected_keys if "attn_mask" not in k and "relative_position_index" not in k]
+    # a Swin-v1 style bias table of another window size is resized bicubically over its (2w-1)^2 grid
+    class V1(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.relative_position_bias_table = torch.nn.Parameter(torch.zeros(27 * 27, 4))
+            self.head = torch.nn.Linear(8, 2)
+    t1 = torch.randn(13 * 13, 4, generator=g)
+    torch.save({"model": {"relative_position_bias_table": t1, "head.weight": torch.zeros(2, 8), "head.bias": torch.zeros(2)}}, f)
+    v1 = V1()
+    um.load_pretrained(cfg, v1, logging.getLogger("t"))
+    ref = torch.nn.functional.interpolate(t1.t().reshape(1, 4, 13, 13), size=(27, 27), mode="bicubic").reshape(4, 27 * 27).t()
+    assert torch.allclose(v1.relative_position_bias_table.data, ref)
+    # a file that has nothing to do with the model is refused instead of "loaded successfully"
+    torch.save({"model": {"totally.unrelated": torch.zeros(3)}}, f)
+    with pytest.raises(RuntimeError):
+        um.load_pretrained(cfg, _mini_swin(), logging.getLogger("t"))
+
+
+def test_fused_model_loads_reference_keyed_files(tmp_path):
+    """The three artefacts of the reference pipeline go into the fused model: a Swin `ckpt['model']`, a MyUniXcoder `pytorch_model.bin`
+    with separate query / key / value, and the fusion head's `mymodel.pth` whose keys carry no `head.` prefix (utils_multi.py:139-152);
+    load_checkpoint on the latter remaps instead of silently matching nothing."""
+    import logging
+    from mvuld_amd import utils_multi as um
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import Multi_DefectModel_new_GCN
+    cfg_file = os.path.join(ROOT, "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    cfg = get_config(types.SimpleNamespace(cfg=cfg_file, opts=["FUSED.DTYPE", "fp32"], batch_size=2, local_rank=0))
+    fused = build_fused_model(cfg)
+    g = torch.Generator().manual_seed(9)
+    rnd = lambda sd: {k: (torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    swin_sd, uni_sd = rnd(fused.swin.state_dict()), rnd(fused.unixcoder.state_dict())
+    head_sd = rnd(Multi_DefectModel_new_GCN(types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))).state_dict())
+    assert "encoder.encoder.layer.0.attention.self.query.weight" in uni_sd and "gat.fc.weight" in head_sd
+    fs, fu, fh = (str(tmp_path / n) for n in ("swin.pth", "pytorch_model.bin", "mymodel.pth"))
+    torch.save({"model": swin_sd}, fs)
+    torch.save(uni_sd, fu)
+    torch.save({"model": head_sd, "epoch": 4}, fh)
+    um.load_fused_parts(fused, swin_ckpt=fs, unixcoder_bin=fu, head_ckpt=fh, logger=logging.getLogger("t"))
+    own = fused.state_dict()
+    for k, v in swin_sd.items():
+        if not k.endswith("relative_coords_table"):
+            assert torch.equal(own["swin." + k], v), k
+    for k, v in uni_sd.items():
+        assert torch.equal(own["unixcoder." + k], v), k
+    for k, v in head_sd.items():
+        assert torch.equal(own["head." + k], v), k
+    # resume path: the reference's head-only mymodel.pth into the fused model
+    fused2 = build_fused_model(cfg)
+    cfg.defrost(); cfg.MODEL.MULTI.RESUME = fh; cfg.EVAL_MODE = True; cfg.freeze()
+    um.load_checkpoint(cfg, fused2, None, None, None, logging.getLogger("t"))
+    assert torch.equal(fused2.state_dict()["head.gat.fc.weight"], head_sd["gat.fc.weight"])
