@@ -120,6 +120,10 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
                           const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                           float* dlogit_scale, int dtype, mvuld_stream_t stream);
 
+/* attn_drop_p / drop_seed (modes 1, 2): dropout on the attention probabilities (HF attention_probs_dropout_prob, active when the
+ * text encoder trains: RobertaConfig built at unixcoder.py:107-110): kept probabilities are scaled by 1/(1-p) before they multiply
+ * V, the softmax normalisation is untouched; the mask is a counter-based hash of (seed, batch, head, query, key), regenerated by
+ * the backward passes from the same seed.  p = 0 switches it off. */
 /* mode 2 (matrix-core kernels only): mode 1 over PACKED sequences: `valid` carries cu [B+1], N = the longest sequence allowed
  * (sizes LDS and the lse rows: lse is [B, H, N]), `res` = total packed tokens; every packed token is a valid key. */
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
@@ -129,13 +133,13 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
  * (<= B*nW*H*2 of them), summed by a second kernel; without it every workgroup adds its table with device atomics. */
 int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
-                        void* out, float* lse, int dtype, mvuld_stream_t stream);
+                        void* out, float* lse, float attn_drop_p, uint64_t drop_seed, int dtype, mvuld_stream_t stream);
 int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, int nW, int ws);   /* size of `ws_part` */
 int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                         float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes,
-                        int passes, int dtype, mvuld_stream_t stream);
+                        int passes, float attn_drop_p, uint64_t drop_seed, int dtype, mvuld_stream_t stream);
 /* passes: 1 = delta + dQ + dK/dV, 2 = bias-table gradient (mode 0; reads ws_delta / ws_qt written by pass 1), 3 = both.
  * The bias-table gradient feeds nothing else in backward, so a caller may issue pass 2 later, on another stream. */
 
@@ -172,6 +176,10 @@ int mvuld_embed_fwd(const int64_t* ids, const int* pos, const float* word, const
                     void* out, int64_t ntok, int H, int vocab, int maxpos, int dtype, mvuld_stream_t stream);
 int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* dword, float* dposw, int64_t ntok, int H,
                     int vocab, int maxpos, int dtype, mvuld_stream_t stream);
+
+/* DropPath factors of a whole forward in one launch: out[k*B + b] = keep(seed, k, b) / (1 - rates[k]) (timm DropPath semantics,
+ * swin_transformer_v2.py:301,304); rates [nblk] fp32 on the device (< 1), counter-based hash, no host RNG or copy. */
+int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, mvuld_stream_t stream);
 
 /* y[i] = x[i] * s[0], s one fp32 on the device: upstream gradient of the scalar loss applied to dlogits (autograd of
  * CrossEntropyLoss when the loss is scaled or summed with other terms, main_bigvul.py:331-333) */

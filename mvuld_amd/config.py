@@ -163,7 +163,10 @@ _DEFAULTS = {
         "SYNTHETIC": True,         # synthetic Big-Vul-shaped data (there is no dataset on the box)
         "SYNTH_TRAIN": 256, "SYNTH_VAL": 64, "SYNTH_TEST": 64,
         "SEQ_LEN": 512, "NODES_LO": 150, "NODES_HI": 250,
-        "TEXT": {"VOCAB": 51416, "HIDDEN": 768, "LAYERS": 12, "HEADS": 12, "INTERMEDIATE": 3072, "MAX_POS": 1026},
+        # HIDDEN_DROPOUT / ATTN_DROPOUT: HF RobertaConfig defaults (unixcoder.py:107-110 builds the model from that config); active
+        # whenever the text encoder is in train() mode, as it is in the fused step
+        "TEXT": {"VOCAB": 51416, "HIDDEN": 768, "LAYERS": 12, "HEADS": 12, "INTERMEDIATE": 3072, "MAX_POS": 1026,
+                 "HIDDEN_DROPOUT": 0.1, "ATTN_DROPOUT": 0.1},
     },
 }
 

@@ -24,7 +24,16 @@ struct AttnGeom {
     float scale;
     const int* cu;          // MODE 1, packed (varlen) sequences: cu[b] .. cu[b+1] are the token rows of sequence b; null = dense [B, N]
     int64_t tok0;           // MODE 1: first token row of the workgroup's sequence (set inside the kernels)
+    // MODE 1, attention-probability dropout (HF attention_probs_dropout_prob): keep(b,h,q,k) = hash(seed, element) >= thr, kept
+    // probabilities scaled by inv = 1/(1-p); thr = 0 switches it off.  Counter-based: the backward passes regenerate the mask.
+    unsigned drop_thr, drop_seed;
+    float drop_inv;
 };
+__device__ __forceinline__ bool am_keep(unsigned elem, unsigned seed, unsigned thr) {
+    unsigned x = elem ^ seed;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x >= thr;
+}
 
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
@@ -183,10 +192,11 @@ __device__ __forceinline__ float am_mask(float s, int ki, int regq, int vq) {
 
 // one block of NT 16-key tiles (NT = 4: 64 keys, NT = 2: 32 keys) of the online-softmax forward.  The softmax denominator rides
 // the matrix cores too: lacc = ones . P^T accumulates sum_k p~ (the bf16-rounded p that also multiplies V) next to O^T.
-template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = false>
 __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
                                              const bf16x8_t (&qf)[HD / 32], const char* tabq, int regq, int vq, int lane, float& m,
-                                             f32x4_t& lacc, f32x4_t (&oacc)[HD / 16], const bf16x8_t& ones) {
+                                             f32x4_t& lacc, f32x4_t (&oacc)[HD / 16], const bf16x8_t& ones, unsigned ebase = 0,
+                                             unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT];
@@ -211,15 +221,23 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
     bm = max4g(bm);
     const float mn = fmaxf(m, bm);
     const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    bf16x8_t pb[NT / 2];
+    bf16x8_t pb[NT / 2], pu[DROP ? NT / 2 : 1];      // pb multiplies V (dropped-out when DROP); the denominator sums the undropped pu
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pb[t >> 1][(t & 1) * 4 + r] = (bf16)__builtin_amdgcn_exp2f(s[t][r] - mn);
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[t][r] - mn);
+            if (DROP) {
+                pu[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+                pb[t >> 1][(t & 1) * 4 + r] = (bf16)(am_keep(ebase + kb + 16 * t + 4 * fg + r, dseed, dthr) ? p * dinv : 0.f);
+            } else {
+                pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+            }
+        }
     m = mn;
     lacc *= alpha;
 #pragma unroll
-    for (int pr = 0; pr < NT / 2; ++pr) lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[pr], lacc, 0, 0, 0);
+    for (int pr = 0; pr < NT / 2; ++pr) lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, DROP ? pu[pr] : pb[pr], lacc, 0, 0, 0);
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d) {
         oacc[d] *= alpha;
@@ -247,8 +265,10 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
     const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;          // lse rows keep the launch's N as their stride
+    const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    const bool drop = MODE == 1 && g.drop_thr != 0;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
@@ -305,7 +325,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
-        if (g4) {
+        if (MODE == 1 && drop) {
+            const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;           // element (b, h, q, k) -> 32-bit counter
+            for (; kb < nfull64; kb += 64)
+                am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+            for (; kb < Np; kb += 32)
+                am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+        } else if (g4) {
             for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
             for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
         } else {
@@ -347,10 +373,11 @@ __global__ __launch_bounds__(256) void attn_delta_k(const bf16* __restrict__ out
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
 // one block of NT key tiles: dS^T = P^T o (dP^T - delta), dQ^T += K^T . dS^T   (scores in log2 units, gradients in natural units)
-template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = false>
 __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
                                             const bf16x8_t (&qf)[HD / 32], const bf16x8_t (&dof)[HD / 32], const char* tabq, int regq, int vq,
-                                            float L2q, const f32x4_t& negD, int lane, f32x4_t (&dq)[HD / 16]) {
+                                            float L2q, const f32x4_t& negD, int lane, f32x4_t (&dq)[HD / 16], unsigned ebase = 0,
+                                            unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
@@ -360,7 +387,7 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
         const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
         ki[t][0] = inf.x; ki[t][1] = inf.y; ki[t][2] = inf.z; ki[t][3] = inf.w;
         s[t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq);       // bias and -delta are accumulator inits, not VALU ops
-        dp[t] = negD;
+        dp[t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : negD;         // with dropout the mask sits between dO.V^T and -delta
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             const int o = (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
@@ -375,7 +402,9 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
         for (int r = 0; r < 4; ++r) {
             float sv = s[t][r];
             if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, ki[t][r], regq, vq);      // padding keys -> NEG_BIG -> p = 0
-            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(__builtin_amdgcn_exp2f(sv - L2q) * dp[t][r]);
+            float dpv = dp[t][r];
+            if (DROP) dpv = (am_keep(ebase + kb + 16 * t + 4 * fg + r, dseed, dthr) ? dpv * dinv : 0.f) + negD[0];
+            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(__builtin_amdgcn_exp2f(sv - L2q) * dpv);
         }
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d)
@@ -405,8 +434,10 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
     const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
+    const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    const bool drop = MODE == 1 && g.drop_thr != 0;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
@@ -466,7 +497,13 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
-        if (g4) {
+        if (MODE == 1 && drop) {
+            const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;
+            for (; kb < nfull64; kb += 64)
+                am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+            for (; kb < Np; kb += 32)
+                am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+        } else if (g4) {
             for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
             for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
         } else {
@@ -730,11 +767,12 @@ __global__ __launch_bounds__(256) void attn_dbias_reduce_k(const float* __restri
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // per-query info word Qi: MODE 0: 4*(iy*(2w-1)+ix + C0) | region << 16 (| AM_PAD); MODE 1: valid (| AM_PAD).  tabk = (char*)tab - 4*bk.
 // Qd holds MINUS delta: it is the initial accumulator of the dP = dO.V^T product, as the bias is of S = Q~.K^T.
-template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4>
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = false>
 __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const bf16* __restrict__ Ds, const int* __restrict__ Qi,
                                              const float* __restrict__ Ql, const float* __restrict__ Qd, int qb, const bf16x8_t (&kf)[HD / 32],
                                              const bf16x8_t (&vf)[HD / 32], const char* tabk, int regk, int vk, int lane,
-                                             f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16]) {
+                                             f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16], unsigned ebase = 0, unsigned NL = 0,
+                                             unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
     constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
@@ -744,7 +782,8 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
         const int4 inf = *(const int4*)(Qi + qb + 16 * t + 4 * fg);
         qi[t][0] = inf.x; qi[t][1] = inf.y; qi[t][2] = inf.z; qi[t][3] = inf.w;
         s[t] = am_bias4<MODE, MASK, TAIL, G4>(qi[t], tabk);
-        dp[t] = *(const f32x4_t*)(Qd + qb + 16 * t + 4 * fg);
+        const f32x4_t nD = *(const f32x4_t*)(Qd + qb + 16 * t + 4 * fg);
+        dp[t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : nD;
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             const int o = (qb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
@@ -762,8 +801,16 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
             float sv = s[t][r];
             if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, qi[t][r], regk, vk);
             const float p = __builtin_amdgcn_exp2f(sv - L[r]);                 // padding queries -> NEG_BIG -> 0
-            pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
-            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * dp[t][r]);
+            if (DROP) {
+                // element (query qb+16t+4fg+r, this lane's key): ebase already holds (b, h) and the key
+                const bool keep = am_keep(ebase + (unsigned)(qb + 16 * t + 4 * fg + r) * NL, dseed, dthr);
+                const float nd = Qd[qb + 16 * t + 4 * fg + r];
+                pb[t >> 1][(t & 1) * 4 + r] = (bf16)(keep ? p * dinv : 0.f);
+                dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * ((keep ? dp[t][r] * dinv : 0.f) + nd));
+            } else {
+                pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+                dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * dp[t][r]);
+            }
         }
     }
 #pragma unroll
@@ -795,8 +842,10 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int64_t rs = 3 * (int64_t)C;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
     const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
+    const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    const bool drop = MODE == 1 && g.drop_thr != 0;
     int C0 = 0;
     float qmul = g.scale;
     if (MODE == 0) {
@@ -854,7 +903,13 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
         int qb = 0;
-        if (g4) {
+        if (MODE == 1 && drop) {
+            const unsigned eb = (unsigned)lse0 * NL + (unsigned)nkc;             // (b, h) row block + this lane's key; + q * NL per query
+            for (; qb < nfull64; qb += 64)
+                am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, g.drop_seed, g.drop_thr, g.drop_inv);
+            for (; qb < Np; qb += 32)
+                am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, g.drop_seed, g.drop_thr, g.drop_inv);
+        } else if (g4) {
             for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
             for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
         } else {
@@ -961,13 +1016,24 @@ static int am_split(int64_t groups, int ntile) {
         else AM_LAUNCH(KERNEL, 64, 1, bytes, __VA_ARGS__);                            \
     } while (0)
 
+static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed) {
+    g.drop_thr = 0; g.drop_seed = 0; g.drop_inv = 1.f;
+    if (mode >= 1 && p > 0.f) {
+        g.drop_thr = (unsigned)((double)p * 4294967296.0);
+        g.drop_seed = (unsigned)(seed ^ (seed >> 32));
+        g.drop_inv = 1.0f / (1.0f - p);
+    }
+}
+
 extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid, void* out,
-                                   float* lse, int dtype, hipStream_t stream) {
+                                   float* lse, float attn_drop_p, uint64_t drop_seed, int dtype, hipStream_t stream) {
     if (am_check("attn_fwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_fwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && lse && (mode >= 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0};
+    MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_fwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f};
+    am_set_dropout(g, mode, attn_drop_p, drop_seed);
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
@@ -1003,13 +1069,15 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                                    float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int passes,
-                                   int dtype, hipStream_t stream) {
+                                   float attn_drop_p, uint64_t drop_seed, int dtype, hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(passes >= 1 && passes <= 3, "attn_bwd_mfma: passes is a mask of 1 (delta + dQ + dK/dV) and 2 (bias-table gradient)");
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
     MV_CHECK_ARG(mode >= 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0};
+    MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_bwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f};
+    am_set_dropout(g, mode, attn_drop_p, drop_seed);
     int64_t ntok = (int64_t)B * nW * N;
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }
     const int Npad = (N + 31) / 32 * 32;

@@ -211,10 +211,29 @@ __global__ void dropout_k(const T* __restrict__ x, T* __restrict__ y, int64_t n,
         stf(y + i, keep ? ldf(x + i) * inv : 0.f);
     }
 }
+// the same mask, eight bf16 per lane through 16-byte accesses (n % 8 == 0, 16-byte aligned): the text encoder's hidden dropouts
+__global__ void dropout_bf16x8_k(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n8, float p, uint64_t seed) {
+    const float inv = 1.0f / (1.0f - p);
+    const uint32_t thr = (uint32_t)(p * 4294967296.0);
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
+        bf16x8 v = *(const bf16x8*)(x + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool keep = mix32(seed + (uint64_t)(c * 8 + e) * 0x9E3779B97F4A7C15ULL) >= thr;
+            v.v[e] = (bf16)(keep ? (float)v.v[e] * inv : 0.f);
+        }
+        *(bf16x8*)(y + c * 8) = v;
+    }
+}
 extern "C" int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, hipStream_t stream) {
     MV_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
-    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n, p, seed));
+    if (dtype == MVULD_BF16 && n % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        const int grid = (int)min((int64_t)8192, cdiv(n / 8, 256));
+        hipLaunchKernelGGL(dropout_bf16x8_k, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8, p, seed);
+    } else {
+        const int grid = (int)min((int64_t)8192, cdiv(n, 256));
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n, p, seed));
+    }
     MV_LAUNCH_CHECK("dropout");
     return 0;
 }
@@ -720,5 +739,23 @@ extern "C" int mvuld_scale_by_dev(const float* x, const float* s, float* y, int6
     MV_CHECK_ARG(x && s && y && n > 0, "scale_by_dev: bad args");
     hipLaunchKernelGGL(scale_by_dev_k, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, x, s, y, n);
     MV_LAUNCH_CHECK("scale_by_dev");
+    return 0;
+}
+
+// DropPath (stochastic depth, timm semantics: swin_transformer_v2.py:301,304 via timm.models.layers.DropPath): per (block, sample)
+// keep / (1 - rate) factors drawn on the device from the counter hash -- out[k*B + b] = hash(seed, k*B + b) >= rate[k] ? 1/(1-rate[k]) : 0.
+// No host RNG, no host -> device copy in the step.
+__global__ void droppath_scales_k(const float* __restrict__ rates, float* __restrict__ out, int nblk, int B, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblk * B) return;
+    const float p = rates[i / B];
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const bool keep = mix32(seed + (uint64_t)i * 0x9E3779B97F4A7C15ULL) >= thr;
+    out[i] = keep ? 1.0f / (1.0f - p) : 0.f;
+}
+extern "C" int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, hipStream_t stream) {
+    MV_CHECK_ARG(rates && out && nblk > 0 && B > 0, "droppath_scales: bad args");
+    hipLaunchKernelGGL(droppath_scales_k, dim3((unsigned)cdiv((int64_t)nblk * B, 256)), dim3(256), 0, stream, rates, out, nblk, B, seed);
+    MV_LAUNCH_CHECK("droppath_scales");
     return 0;
 }

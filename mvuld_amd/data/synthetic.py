@@ -62,6 +62,20 @@ def make_ids(index: int, length=512, vocab=51416, pad=1, lo=128, salt=0) -> torc
     return ids
 
 
+def make_line_ids(index: int, n_lines: int, length=64, vocab=51416, pad=1, lo=4, salt=0):
+    """Token ids of the source LINES of function `index` (one row per graph node: data_list.py:293-299 encodes every line of the
+    function on its own, padded to a fixed length), with their non-pad counts: ([n_lines, length] int64, [n_lines] int32).
+    Lines are short: lengths ~ U[lo, length]."""
+    tag = f"lines/{index}"
+    lens = synth.ints(tag + "/len", (n_lines,), lo, length + 1, salt)
+    ids = synth.ints(tag + "/tok", (n_lines, length), 5, vocab, salt)
+    ids[:, 0], ids[:, 1], ids[:, 2] = 0, 6, 2
+    col = torch.arange(length)[None, :]
+    ids[col == (lens[:, None] - 1)] = 2
+    ids[col >= lens[:, None]] = pad
+    return ids, lens.to(torch.int32)
+
+
 def make_image(index: int, size=448, salt=0) -> torch.Tensor:
     return synth.tensor(f"img/{index}", (3, size, size), -1.7, 1.7, salt)
 

@@ -88,8 +88,15 @@ def build_fused_model(config):
     ad = act_dtype_of(config)
     if config.FUSED.ENABLE:
         t = config.FUSED.TEXT
+        attn_drop = float(t.ATTN_DROPOUT)
+        if attn_drop > 0.0 and ad != torch.bfloat16:
+            # dropout on attention probabilities lives inside the matrix-core attention kernels (bf16); the fp32 parity mode runs the
+            # VALU kernels and is compared with a dropout-free oracle anyway
+            print(f"FUSED.DTYPE fp32: FUSED.TEXT.ATTN_DROPOUT {attn_drop} -> 0 (not available in the fp32 parity mode)")
+            attn_drop = 0.0
         rc = RobertaConfigLite(vocab_size=t.VOCAB, hidden_size=t.HIDDEN, num_hidden_layers=t.LAYERS, num_attention_heads=t.HEADS,
-                               intermediate_size=t.INTERMEDIATE, max_position_embeddings=t.MAX_POS)
+                               intermediate_size=t.INTERMEDIATE, max_position_embeddings=t.MAX_POS,
+                               hidden_dropout_prob=float(t.HIDDEN_DROPOUT), attention_probs_dropout_prob=attn_drop)
         return FusedMVulD(config, rc, ad)
     return Multi_DefectModel_new_GCN(config=config, act_dtype=ad)
 

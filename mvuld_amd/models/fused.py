@@ -40,19 +40,27 @@ class FusedMVulD(nn.Module):
     def no_weight_decay_keywords(self):
         return self.swin.no_weight_decay_keywords()
 
-    def forward(self, g, images, source_ids, seq_lens=None):
+    def forward(self, g, images, source_ids, seq_lens=None, node_ids=None, node_lens=None):
         """The two encoders are independent until the head: the text encoder runs on a second HIP stream so its kernels fill
         the tails of the image encoder's launches (and vice versa); autograd replays each branch's backward on the stream its
         forward ran on.  The side stream is joined before the head and, in backward, when the text encoder's first op has
         launched its last kernel (its parameter gradients are atomics into the flat store, invisible to autograd's own
         stream bookkeeping).  MVULD_CONCURRENT=0, or the per-launch timing mode, keeps everything on one stream.
         seq_lens (optional, host int tensor [B]): non-pad tokens per function; with it the text encoder runs pad-free on the packed
-        tokens (same sentence vectors: pad rows never reach them, unixcoder.py:35-37); MVULD_PACK_TEXT=0 ignores it."""
+        tokens (same sentence vectors: pad rows never reach them, unixcoder.py:35-37); MVULD_PACK_TEXT=0 ignores it.
+        node_ids / node_lens (optional): token ids [sum N, L] (+ host-side non-pad counts) of the source line behind every graph node;
+        the node features `_UNIX_NODE_EMB` are then computed here, on the device, by the same text encoder (no gradient, as the
+        reference caches them offline: data_list.py:265-317) instead of being read from g.ndata."""
         from .. import hip, ops
         concurrent = images.is_cuda and os.environ.get("MVULD_CONCURRENT", "1") != "0" and not hip.TIMING.enabled
         if os.environ.get("MVULD_PACK_TEXT", "1") == "0":
             seq_lens = None
         self.unixcoder.return_tokens = False                           # only the sentence vector is read here
+        if node_ids is not None:
+            was = self.unixcoder.training
+            self.unixcoder.eval()                                      # offline feature extraction semantics: no dropout, no gradient
+            g.ndata["_UNIX_NODE_EMB"] = self.unixcoder.encode_lines(node_ids, node_lens).float()
+            self.unixcoder.train(was)
         if not concurrent:
             ops.WGRAD_STREAM[0] = None
             ops.on_backward_done("unixcoder", None, key="fused-join")

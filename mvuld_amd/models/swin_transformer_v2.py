@@ -381,7 +381,7 @@ class SwinTransformerV2(nn.Module):
         for i, bly in enumerate(self.layers):
             bly._init_respostnorm()
             bly.blocks[0]._backward_done_tag = f"swin.layers.{i}"      # fired when stage i's backward has launched its last kernel
-        self._dp_gen = torch.Generator().manual_seed(0)
+        self._dp_rates, self._dp_seed = None, 0x0D50F7A7
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -401,13 +401,16 @@ class SwinTransformerV2(nn.Module):
         return {"cpb_mlp", "logit_scale", 'relative_position_bias_table'}
 
     def _droppath_scales(self, B, device):
-        """[n_blocks, B] per-sample keep/(1-p) factors (timm DropPath semantics), one H2D copy per forward."""
+        """[n_blocks, B] per-sample keep/(1-p) factors (timm DropPath semantics), drawn on the device by one kernel launch."""
         rates = [blk.drop_path_rate for layer in self.layers for blk in layer.blocks]
         if not self.training or max(rates) <= 0.0:
             return None
-        r = torch.tensor(rates).view(-1, 1)
-        keep = (torch.rand(len(rates), B, generator=self._dp_gen) >= r).float() / (1.0 - r)
-        return keep.to(device, non_blocking=True)
+        if self._dp_rates is None or self._dp_rates.device != device:
+            self._dp_rates = torch.tensor(rates, dtype=torch.float32).to(device)
+        self._dp_seed = (self._dp_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        out = torch.empty((len(rates), B), dtype=torch.float32, device=device)
+        call("droppath_scales", ptr(self._dp_rates), ptr(out), len(rates), B, self._dp_seed)
+        return out
 
     def forward_features(self, x):
         hip.require_gpu(x)

@@ -76,6 +76,28 @@ class _EmbedFn(torch.autograd.Function):
         return None, None, None, None
 
 
+_SEED = [0xC0DE5EED]
+
+
+def _next_seed():
+    _SEED[0] = (_SEED[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _SEED[0]
+
+
+class _DropoutFn(torch.autograd.Function):
+    """Hidden-state dropout (HF hidden_dropout_prob) with a counter-based mask: backward replays the same (seed, index) hash."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.meta = (p, seed)
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        return ops.dropout(dy.contiguous(), p, seed), None, None
+
+
 class _PackEmbedFn(torch.autograd.Function):
     """Packed variant of _EmbedFn: only the non-pad tokens are embedded; row cu[b] + r of the result is the r-th non-pad token of
     sequence b (the reference computes the pad rows too and never uses them: unixcoder.py:35-37)."""
@@ -154,6 +176,28 @@ class _UnpackFn(torch.autograd.Function):
         return dx, None, None
 
 
+class _PinnedRing:
+    """Small pinned host buffers handed out round-robin: a tiny tensor built on the host every step (cu_seqlens) reaches the device
+    by an ASYNCHRONOUS copy.  (From pageable memory `.to(device)` synchronises the stream: the host would then run in lock-step
+    with the GPU instead of a step or two ahead of it.)  A slot is reused 16 copies later, long after its copy has executed."""
+
+    def __init__(self, slots=16, elems=4096):
+        self.bufs, self.i, self.elems, self.slots = None, 0, elems, slots
+
+    def stage(self, t: torch.Tensor, device):
+        if not torch.cuda.is_available() or device.type != "cuda" or t.numel() > self.elems or t.dtype != torch.int32:
+            return t.to(device)
+        if self.bufs is None:
+            self.bufs = [torch.empty(self.elems, dtype=torch.int32).pin_memory() for _ in range(self.slots)]
+        b = self.bufs[self.i % self.slots][:t.numel()]
+        self.i += 1
+        b.copy_(t)
+        return b.to(device, non_blocking=True)
+
+
+_CU_STAGE = _PinnedRing()
+
+
 class PackedSeqs:
     """cu_seqlens of a packed batch: `cu` int32 [B+1] on the device, total tokens, and the sum of squared lengths."""
 
@@ -172,24 +216,33 @@ class _LayerFn(torch.autograd.Function):
         ad = x.dtype
         sa = layer.attention.self
         qkv = ops.gemm_nt(x, ops.weight(sa.qkv_weight, ad), bias=sa.qkv_bias.data)
+        # dropouts of the HF layer (train mode only): attention probabilities inside the fused kernel, hidden states after the
+        # attention-output and the FFN-output dense (before their residual LayerNorms); counter-based masks, replayed in backward
+        pa = float(cfg.attention_probs_dropout_prob) if layer.training else 0.0
+        ph = float(cfg.hidden_dropout_prob) if layer.training else 0.0
+        if pa > 0.0 and not ops._mfma_attn_ok(ops.AttnGeom(1, B, nh, H // nh, L), ad):
+            raise RuntimeError("attention-probability dropout needs the matrix-core attention path (bf16); set the rate to 0 for the fp32 mode")
+        seeds = (_next_seed(), _next_seed(), _next_seed()) if (pa > 0.0 or ph > 0.0) else (0, 0, 0)
         if isinstance(valid, PackedSeqs):
-            geom = ops.AttnGeom(2, B, nh, H // nh, L, 1, valid.total, 0, 0, 1.0 / math.sqrt(H // nh), sumsq=valid.sumsq)
+            geom = ops.AttnGeom(2, B, nh, H // nh, L, 1, valid.total, 0, 0, 1.0 / math.sqrt(H // nh), sumsq=valid.sumsq, drop_p=pa, drop_seed=seeds[0])
             valid = valid.cu
         else:
-            geom = ops.AttnGeom(1, B, nh, H // nh, L, 1, 0, 0, 0, 1.0 / math.sqrt(H // nh))
+            geom = ops.AttnGeom(1, B, nh, H // nh, L, 1, 0, 0, 0, 1.0 / math.sqrt(H // nh), drop_p=pa, drop_seed=seeds[0])
         cx, lse = ops.attn_fwd(geom, qkv, valid=valid)
         ao = layer.attention.output
         a = ops.gemm_nt(cx, ops.weight(ao.dense.weight, ad), bias=ao.dense.bias.data)
+        a = ops.dropout(a, ph, seeds[1])
         x1, mean1, rstd1, s1 = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps,
                                                  pre=x, want_sum=True)
         it, ot = layer.intermediate, layer.output
         ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device)
         iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
         o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
+        o = ops.dropout(o, ph, seeds[2])
         x2, mean2, rstd2, s2 = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps,
                                                  pre=x1, want_sum=True)
         ctx.save_for_backward(x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2)
-        ctx.layer, ctx.geom = layer, geom
+        ctx.layer, ctx.geom, ctx.hdrop = layer, geom, (ph, seeds[1], seeds[2])
         return x2
 
     @staticmethod
@@ -198,14 +251,17 @@ class _LayerFn(torch.autograd.Function):
         layer, geom = ctx.layer, ctx.geom
         ad = x.dtype
         sa, ao, it, ot = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
-        ds2 = ops.layernorm_bwd(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2)
-        ops.linear_wgrad(ds2, iact, ot.dense.weight, ot.dense.bias)
-        dipre = ops.gemm_nt(ds2, ops.weight_t(ot.dense.weight, ad), epi=hip.EPI_MUL_DGELU, aux=ipre)
+        ph, seed1, seed2 = ctx.hdrop
+        ds2 = ops.layernorm_bwd(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2)      # d(dropout(o) + x1)
+        do = ops.dropout(ds2, ph, seed2)                                                                       # d(o): the residual keeps ds2
+        ops.linear_wgrad(do, iact, ot.dense.weight, ot.dense.bias)
+        dipre = ops.gemm_nt(do, ops.weight_t(ot.dense.weight, ad), epi=hip.EPI_MUL_DGELU, aux=ipre)
         ops.linear_wgrad(dipre, x1, it.dense.weight, it.dense.bias)
         g1 = ops.gemm_nt(dipre, ops.weight_t(it.dense.weight, ad), epi=hip.EPI_ADD_AUX, aux=ds2)
         ds1 = ops.layernorm_bwd(g1, s1, ao.LayerNorm.weight, ao.LayerNorm.bias, mean1, rstd1)
-        ops.linear_wgrad(ds1, cx, ao.dense.weight, ao.dense.bias)
-        dcx = ops.gemm_nt(ds1, ops.weight_t(ao.dense.weight, ad))
+        da = ops.dropout(ds1, ph, seed1)
+        ops.linear_wgrad(da, cx, ao.dense.weight, ao.dense.bias)
+        dcx = ops.gemm_nt(da, ops.weight_t(ao.dense.weight, ad))
         dqkv = ops.attn_bwd(geom, qkv, cx, dcx, lse, valid=valid)
         ops.linear_wgrad(dqkv, x, sa.qkv_weight, sa.qkv_bias)
         dx = ops.gemm_nt(dqkv, ops.weight_t(sa.qkv_weight, ad), epi=hip.EPI_ADD_AUX, aux=ds1)
@@ -333,9 +389,14 @@ class RobertaModel(nn.Module):
         """-> (tokens [B*L, H], valid int32 [B, L])"""
         B, L = source_ids.shape
         x, valid = _EmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, self.embeddings, self.act_dtype)
+        x = self._embedding_dropout(x)
         for layer in self.encoder.layer:
             x = _LayerFn.apply(x, valid, layer, B, L)
         return x, valid
+
+    def _embedding_dropout(self, x):
+        p = float(self.config.hidden_dropout_prob) if self.training else 0.0      # HF RobertaEmbeddings: LayerNorm, then dropout
+        return _DropoutFn.apply(x, p, _next_seed()) if p > 0.0 else x
 
     def can_pack(self):
         return self.act_dtype == torch.bfloat16 and ops.ATTN_IMPL[0] == "auto"
@@ -350,7 +411,7 @@ class RobertaModel(nn.Module):
         cu_host[1:] = torch.cumsum(lens, 0)
         T = int(cu_host[-1])
         assert T > 0, "every sequence is empty"
-        return PackedSeqs(cu_host.to(device), T, float((lens * lens).sum()))
+        return PackedSeqs(_CU_STAGE.stage(cu_host, torch.device(device)), T, float((lens * lens).sum()))
 
     def encode_packed(self, source_ids, seq_lens):
         """Pad-free encoder pass.  seq_lens: per-sequence count of non-pad tokens, a HOST int tensor / list (the data loader
@@ -361,6 +422,7 @@ class RobertaModel(nn.Module):
         assert packed.cu.numel() == B + 1, "seq_lens does not match source_ids"
         T = packed.total
         x, rowmap = _PackEmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, packed.cu, T, self.embeddings, self.act_dtype)
+        x = self._embedding_dropout(x)
         for layer in self.encoder.layer:
             x = _LayerFn.apply(x, packed, layer, B, L)
         return x, packed, rowmap
@@ -411,6 +473,24 @@ class MyUniXcoder(nn.Module):
         source_ids = input_ids.view(-1, self.max_source_length)
         _, vec = self.get_xcode_vec(source_ids)
         return vec, labels
+
+    def encode_lines(self, line_ids, line_lens=None, chunk=8192):
+        """Node embeddings of a graph: one sentence vector per source line (the rows `myEncode` produces for data_list.py:293-299,
+        cached offline by the reference), from the lines' token ids [n_lines, L].  With `line_lens` (host-side non-pad counts) the
+        lines are packed: a batch of 200 lines of ~15 tokens costs what 6 padded 512-token rows would.  No gradients (the reference
+        computes them offline under torch.no_grad)."""
+        outs = []
+        with torch.no_grad():
+            for a in range(0, line_ids.shape[0], chunk):
+                ids = line_ids[a:a + chunk]
+                lens = None if line_lens is None else torch.as_tensor(line_lens)[a:a + chunk]
+                keep, self.return_tokens = self.return_tokens, False
+                try:
+                    _, vec = self.get_xcode_vec(ids, lens)
+                finally:
+                    self.return_tokens = keep
+                outs.append(vec)
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
     def myEncode(self, sents: list):
         if self.tokenize is None:

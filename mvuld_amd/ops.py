@@ -394,9 +394,10 @@ def dropout(x, p, seed):
 class AttnGeom:
     """Geometry of one fused-attention call (see include/mvuld_hip.h)."""
 
-    def __init__(self, mode, B, H, hd, N, nW=1, res=0, ws=0, shift=0, scale=1.0, sumsq=0):
+    def __init__(self, mode, B, H, hd, N, nW=1, res=0, ws=0, shift=0, scale=1.0, sumsq=0, drop_p=0.0, drop_seed=0):
         self.mode, self.B, self.H, self.hd, self.N, self.nW = mode, B, H, hd, N, nW
         self.res, self.ws, self.shift, self.scale = res, ws, shift, scale
+        self.drop_p, self.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF     # attention-probability dropout (modes 1, 2)
         self.sumsq = sumsq              # mode 2: sum of squared sequence lengths (algorithmic FLOP count of the instrumented step)
 
     def args(self):
@@ -425,7 +426,12 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     if g.mode == 2 and name != "attn_fwd_mfma":
         raise RuntimeError("packed (mode 2) attention exists on the matrix-core path only (bf16)")
     hip.TIMING.annotate(name, 4.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
-    call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
+    if name == "attn_fwd_mfma":
+        call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), g.drop_p, g.drop_seed, dt(qkv))
+    else:
+        if g.drop_p > 0.0:
+            raise RuntimeError("attention-probability dropout exists on the matrix-core attention path only (bf16)")
+        call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), dt(qkv))
     return out, lse
 
 
@@ -444,11 +450,11 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         wg = wgrad_stream_for_current() if g.mode == 0 else None
         if g.mode != 0 or wg is None:
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
-            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, dt(qkv))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed, dt(qkv))
             return dqkv
         # The bias-table gradient feeds nothing else in backward: dQ / dK / dV stay on this stream, the table pass (and whatever
         # the caller does with dtable16 afterwards: see bias_stream) goes to the weight-gradient stream.
-        call("attn_bwd_mfma", *args, None, 0, 1, dt(qkv))
+        call("attn_bwd_mfma", *args, None, 0, 1, 0.0, 0, dt(qkv))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(qkv.device))
         wg.wait_event(ev)
@@ -456,7 +462,7 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
             t.record_stream(wg)
         with torch.cuda.stream(wg):
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))
-            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, dt(qkv))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, 0.0, 0, dt(qkv))
         BIAS_STREAM[0] = wg
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)

@@ -108,9 +108,9 @@ def _rob_ids(vocab, L, lens, tag, pad=1):
     return torch.stack(rows)
 
 
-def _unix(kw, dtype, gpu):
+def _unix(kw, dtype, gpu, hidden_drop=0.0, attn_drop=0.0):
     from mvuld_amd.models.unixcoder import RobertaConfigLite, RobertaModel, MyUniXcoder
-    rc = RobertaConfigLite(**kw)
+    rc = RobertaConfigLite(**kw, hidden_dropout_prob=hidden_drop, attention_probs_dropout_prob=attn_drop)     # parity: the oracle has no dropout
     m = MyUniXcoder(RobertaModel(rc, dtype), rc)
     sd, _ = load_synth_into(m)
     return m.to(gpu), sd, rc
@@ -181,6 +181,127 @@ def test_unixcoder_packed_gradients_vs_oracle(gpu):
     worst.sort(reverse=True)
     print("[unixcoder packed grads] worst: " + ", ".join(f"{n}={e:.2e}" for e, n in worst[:6]))
     assert worst[0][0] < 8e-2, worst[:6]
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_unixcoder_dropout_statistics_and_backward_replay(gpu, packed):
+    """RoBERTa's dropouts (HF defaults 0.1; config built at unixcoder.py:107-110) with counter-based masks.
+    (1) eval mode ignores them (bit-identical to p = 0);  (2) the attention-probability dropout is unbiased: E[dropout(P)] = P, so
+    the mean over many seeds of the attention output approaches the p = 0 output, and one draw differs from it by the expected
+    sqrt(p/(1-p)) scale;  (3) backward regenerates the forward's masks: with the same seeds the gradient of sum(out * w) equals a
+    central finite difference of the SAME masked function along a random direction of the qkv input."""
+    from mvuld_amd import ops
+    B, H, hd, L = 3, 2, 64, 96
+    lens = [96, 50, 7]
+    g = torch.Generator().manual_seed(21)
+    T = sum(lens) if packed else B * L
+    qkv = (torch.randn(T, 3 * H * hd, generator=g) * 0.7).to(torch.bfloat16).to(gpu)
+    if packed:
+        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=gpu)
+        mk = lambda p, seed: ops.AttnGeom(2, B, H, hd, L, 1, T, 0, 0, hd ** -0.5, drop_p=p, drop_seed=seed)
+        valid = cu
+    else:
+        valid = torch.zeros(B, L, dtype=torch.int32)
+        for b, n in enumerate(lens):
+            valid[b, :n] = 1
+        valid = valid.to(gpu)
+        mk = lambda p, seed: ops.AttnGeom(1, B, H, hd, L, 1, 0, 0, 0, hd ** -0.5, drop_p=p, drop_seed=seed)
+    rows = torch.ones(T, dtype=torch.bool) if packed else valid.bool().view(-1).cpu()
+    base, _ = ops.attn_fwd(mk(0.0, 0), qkv, valid=valid)
+    base = base.float().cpu()[rows]
+    p = 0.25
+    acc = torch.zeros_like(base)
+    n_draws = 64
+    for sd in range(n_draws):
+        o, _ = ops.attn_fwd(mk(p, 1000 + sd), qkv, valid=valid)
+        o = o.float().cpu()[rows]
+        if sd == 0:
+            one = o
+        acc += o
+    mean = acc / n_draws
+    scale = float(base.abs().mean())
+    assert float((one - base).abs().mean()) > 0.05 * scale                  # a single draw is really perturbed
+    assert float((mean - base).abs().mean()) < 0.35 * float((one - base).abs().mean())      # ~1/sqrt(64) of it on average: unbiased
+    # same seed -> same mask
+    o2, _ = ops.attn_fwd(mk(p, 1000), qkv, valid=valid)
+    assert torch.equal(o2.float().cpu()[rows], one)
+    # forward AND backward against autograd on the plain formulation with the mask rebuilt on the host from the same counter hash
+    # (element (b, h, q, k) -> ((b*H + h)*L + q)*L + k, 32-bit): any disagreement between the three passes' masks shows here
+    def keep_mask(b, h, n, seed):
+        q = np.arange(n, dtype=np.uint64)[:, None]
+        k = np.arange(n, dtype=np.uint64)[None, :]
+        e = (((np.uint64(b * H + h) * np.uint64(L) + q) * np.uint64(L) + k) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x = e ^ np.uint32((seed ^ (seed >> 32)) & 0xFFFFFFFF)
+        x ^= x >> np.uint32(16); x = (x.astype(np.uint64) * np.uint64(0x7feb352d) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x ^= x >> np.uint32(15); x = (x.astype(np.uint64) * np.uint64(0x846ca68b) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return torch.from_numpy(x >= np.uint32(int(p * 4294967296.0)))
+    seed = 77
+    w = torch.randn(T, H * hd, generator=g).to(torch.bfloat16)
+    w[~rows] = 0          # pad query rows never reach the loss in the model (masked mean): no upstream gradient there
+    out, lse = ops.attn_fwd(mk(p, seed), qkv, valid=valid)
+    dqkv = ops.attn_bwd(mk(p, seed), qkv, out, w.to(gpu), lse, valid=valid).float().cpu()
+    x = qkv.float().cpu().requires_grad_(True)
+    ref_rows = []
+    row0 = 0
+    for b, n in enumerate(lens):
+        r0 = row0 if packed else b * L
+        blk = x[r0:r0 + n].view(n, 3, H, hd)
+        heads = []
+        for h in range(H):
+            qh, kh, vh = blk[:, 0, h], blk[:, 1, h], blk[:, 2, h]
+            P = torch.softmax(qh @ kh.t() * hd ** -0.5, dim=-1)
+            heads.append((P * keep_mask(b, h, n, seed) / (1 - p)) @ vh)
+        ref_rows.append((r0, n, torch.cat(heads, 1)))
+        row0 += n
+    loss = sum((o * w[r0:r0 + n].float()).sum() for r0, n, o in ref_rows)
+    loss.backward()
+    for r0, n, o in ref_rows:
+        assert rel(out[r0:r0 + n], o) < 3e-2
+        assert rel_l2(dqkv[r0:r0 + n], x.grad[r0:r0 + n]) < 5e-2
+
+
+def test_unixcoder_hidden_dropout_train_vs_eval(gpu):
+    """eval() ignores every dropout; train() with p > 0 changes the sentence vector, is reproducible only through the seed counter, and
+    its backward runs (hidden dropouts replayed on the gradients; finite gradients everywhere)."""
+    m, _, rc = _unix(ROB_TINY, torch.bfloat16, gpu, hidden_drop=0.1, attn_drop=0.1)
+    m0, _, _ = _unix(ROB_TINY, torch.bfloat16, gpu)
+    ids = _rob_ids(rc.vocab_size, 128, [128, 77, 5], "roberta_tiny").to(gpu)
+    m.eval(); m0.eval()
+    with torch.no_grad():
+        assert torch.equal(m.get_xcode_vec(ids)[1], m0.get_xcode_vec(ids)[1])
+    m.train()
+    _, s1 = m.get_xcode_vec(ids, seq_lens=[128, 77, 5])
+    _, s2 = m.get_xcode_vec(ids, seq_lens=[128, 77, 5])
+    with torch.no_grad():
+        ref = m0.get_xcode_vec(ids)[1]
+    assert not torch.equal(s1, s2) and 1e-3 < rel(s1, ref) < 0.5
+    s1.float().sum().backward()
+    for n, p_ in m.named_parameters():
+        if p_.requires_grad and not n.startswith("classifier") and p_.grad is not None:
+            assert bool(torch.isfinite(p_.grad).all()), n
+
+
+def test_unixcoder_per_line_node_embeddings_vs_oracle(gpu):
+    """per-line UniXcoder node embeddings (unixcoder.py:56-68 as driven by data_list.py:293-299) from a RAGGED
+    batch of short lines through the packed varlen path -- 333 lines of 1..64 tokens, incl. length-1 and full-length rows -- vs the
+    fp32 oracle on the same ids; and the fused model fed line ids must produce the logits it produces from those embeddings."""
+    from oracle import roberta_ref
+    from mvuld_amd.data import synthetic
+    m, sd, rc = _unix(ROB_TINY, torch.bfloat16, gpu)
+    m.eval()
+    ids, lens = synthetic.make_line_ids(4242, 333, length=64, vocab=rc.vocab_size, lo=1)
+    assert int(lens.min()) == 1 and int(lens.max()) == 64 and bool(((ids != 1).sum(1) == lens).all())      # one-token and full-length lines included
+    cfg = roberta_ref.RobertaCfg(vocab_size=1000, hidden_size=128, num_layers=2, num_heads=2, intermediate_size=512, max_position=130)
+    with torch.no_grad():
+        _, ref = roberta_ref.unixcoder_sentence(sd, ids, cfg)
+    emb = m.encode_lines(ids.to(gpu), lens)
+    assert emb.shape == (333, 128)
+    e = rel(emb, ref)
+    print(f"[per-line node embeddings, 333 ragged lines] rel err vs oracle {e:.3e}")
+    assert e < 3e-2
+    assert rel(m.encode_lines(ids.to(gpu), lens, chunk=100), emb) < 1e-6          # chunking is only a batching choice
+    assert rel(m.encode_lines(ids.to(gpu)), ref) < 3e-2                          # padded route, same answer
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
