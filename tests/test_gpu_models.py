@@ -374,6 +374,100 @@ def test_head_logits_vs_golden(gpu, dtype, mode):
     assert err < lim
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_head_fp32_order_one_rsgcn_bn_scales(gpu, mode):
+    """The synthetic Rs_GCN residual-BatchNorm scales are drawn small (0.05-0.15) so that the 8-block chain stays well conditioned in
+    bf16.  This case puts them at O(1) (0.6 .. 1.4, where every block amplifies a perturbation ~1.4x) in the fp32 mode: the kernels
+    themselves are exact to fp32 rounding outside the hand-picked regime too."""
+    from oracle import head_ref
+    m, sd = _head(torch.float32, gpu)
+    for k in range(1, 9):
+        key = f"Rs_GCN_{k}.W.1.weight"
+        w = 0.6 + 0.8 * synth.tensor(f"o1/{key}", tuple(sd[key].shape), 0.0, 1.0)
+        sd[key] = w
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    m = m.to(gpu)
+    from mvuld_amd import ops
+    ops.bump_weight_epoch()
+    m.train(mode == "train")
+    g, img, txt = _head_inputs()
+    with torch.no_grad():
+        ref = head_ref.head_forward(sd, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt,
+                                    training=(mode == "train"))
+        lg = m(g.to(gpu), img.to(gpu), txt.to(gpu))
+    err = float((lg.float().cpu() - ref).abs().max())
+    print(f"[head fp32, O(1) Rs_GCN BN scales, {mode}] max abs logit err = {err:.3e} (logit scale {float(ref.abs().max()):.3f})")
+    assert err < 1e-3
+
+
+def test_swin_full_size_block_gradients_vs_oracle(gpu):
+    """Gradient parity at the model's real widths, one block at a time (the whole-model gradient checks run reduced geometries): a
+    base-448 STAGE-2 block (784 tokens x 512 channels, 16 heads, one 28x28 window) and a STAGE-1 block with the cyclic shift (56x56
+    tokens x 256 channels, 8 heads, four shifted 28x28 windows with the region mask), bf16 product path vs fp32 oracle autograd:
+    output, input gradient, every parameter gradient."""
+    from oracle import swin_ref
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerBlock
+    from mvuld_amd import ops
+    for tag, dim, res, heads, shift, B in (("s2", 512, 28, 16, 0, 2), ("s1-shifted", 256, 56, 8, 14, 1)):
+        blk = SwinTransformerBlock(dim, (res, res), heads, window_size=28, shift_size=shift, pretrained_window_size=12)
+        sd, _ = load_synth_into(blk, prefix=f"fullblk/{tag}/")
+        sd = {k[len(f"fullblk/{tag}/"):]: v for k, v in sd.items()}
+        blk = blk.to(gpu).train()
+        ops.bump_weight_epoch()
+        x = synth.tensor(f"fullblk/{tag}/x", (B, res * res, dim), -1, 1)
+        wv = synth.tensor(f"fullblk/{tag}/w", (B, res * res, dim), -1, 1)
+        sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        yr = swin_ref.swin_block(sdr, "", xr, res, dim, heads, 28, shift, 12)
+        (yr * wv).sum().backward()
+        xg = x.to(gpu).to(torch.bfloat16).view(B * res * res, dim).requires_grad_(True)
+        y = blk(xg, B, None)
+        (y.float() * wv.to(gpu).view(B * res * res, dim)).sum().backward()
+        assert rel(y.view(B, res * res, dim), yr) < 3e-2
+        worst = [(rel_l2(xg.grad.view(B, res * res, dim), xr.grad), "input")]
+        for n, p in blk.named_parameters():
+            worst.append((rel_l2(p.grad, sdr[n].grad), n))
+        worst.sort(reverse=True)
+        print(f"[swin full-size block {tag}] out rel {rel(y.view(B, res * res, dim), yr):.2e}; worst grads: " + ", ".join(f"{n}={e:.2e}" for e, n in worst[:5]))
+        assert worst[0][0] < 1.5e-1, worst[:5]            # cpb-MLP / logit_scale: sums of ~1e5 bf16-noisy terms that largely cancel
+        assert sorted(worst)[len(worst) // 2][0] < 3e-2
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_roberta_full_size_layer_gradients_vs_oracle(gpu, packed):
+    """One RoBERTa layer at the real width (768 hidden, 12 heads, 3072 intermediate, 512 positions, vocabulary 51416), ragged batch
+    [512, 301]: sentence vector and every parameter gradient, bf16 product path (padded and pad-free) vs fp32 oracle autograd."""
+    from oracle import roberta_ref
+    kw = dict(num_hidden_layers=1)
+    m, sd, rc = _unix(kw, torch.bfloat16, gpu)
+    m.train()
+    lens = [512, 301]
+    ids = _rob_ids(rc.vocab_size, 512, lens, "roberta_full1")
+    wv = synth.tensor("rob/gradw_full", (2, 768))
+    cfg = roberta_ref.RobertaCfg(num_layers=1)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, sr = roberta_ref.unixcoder_sentence(sdr, ids, cfg)
+    (sr * wv).sum().backward()
+    m.return_tokens = False
+    _, s_ = m.get_xcode_vec(ids.to(gpu), seq_lens=lens if packed else None)
+    (s_.float() * wv.to(gpu)).sum().backward()
+    assert rel(s_, sr) < 3e-2
+    worst = []
+    for n, p in m.named_parameters():
+        if not p.requires_grad or n.startswith("classifier"):
+            continue
+        if n.endswith("qkv_weight") or n.endswith("qkv_bias"):
+            base = n[:-len("qkv_weight")] if n.endswith("qkv_weight") else n[:-len("qkv_bias")]
+            suf = "weight" if n.endswith("qkv_weight") else "bias"
+            g_ref = torch.cat([sdr[f"{base}{q}.{suf}"].grad for q in ("query", "key", "value")], 0)
+        else:
+            g_ref = sdr[n].grad
+        worst.append((rel_l2(p.grad, g_ref), n))
+    worst.sort(reverse=True)
+    print(f"[roberta full-size layer packed={packed}] worst: " + ", ".join(f"{n}={e:.2e}" for e, n in worst[:6]))
+    assert worst[0][0] < 8e-2, worst[:6]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_head_gradients_vs_oracle(gpu, dtype):
     from oracle import head_ref
@@ -497,9 +591,12 @@ def test_fused_train_step_vs_oracle(gpu, dtype):
     print(f"[fused {dtype}] logits err={e_log:.3e} loss {float(loss):.5f} vs {float(loss_r):.5f} grad_norm {float(norm):.4f} vs {float(norm_r):.4f}")
     # bf16 + train-mode BatchNorm over FOUR samples is a noise amplifier (see test_head_logits_vs_golden); the bf16 bound
     # of the north_star (1e-2) is checked in eval mode below, the train-mode check is a sanity band
-    assert e_log < (1e-3 if dtype == torch.float32 else 3e-1)
-    assert abs(float(loss) - float(loss_r)) < (1e-4 if dtype == torch.float32 else 1e-1)
-    assert abs(float(norm) - float(norm_r)) / float(norm_r) < (1e-3 if dtype == torch.float32 else 0.5)
+    # bf16 bounds = ~2.5x what the error budget of DESIGN.md section 5 predicts and the runs measure on this geometry (bf16 weights +
+    # residual stream ~1.2e-2 on the encoder features, times the 1/std amplification of train-mode BatchNorm over four samples:
+    # logits 2-4e-2, loss 4e-4..3e-3, gradient norm 2-5 %)
+    assert e_log < (1e-3 if dtype == torch.float32 else 1e-1)
+    assert abs(float(loss) - float(loss_r)) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert abs(float(norm) - float(norm_r)) / float(norm_r) < (1e-3 if dtype == torch.float32 else 0.1)
     if dtype == torch.bfloat16:
         with torch.no_grad():
             model.eval()
@@ -760,3 +857,26 @@ def test_fused_inference_batch256_hipgraph(gpu):
             small = model(g2, im2.to(gpu), id2.to(gpu)).float()
             # identical arithmetic per function; GEMM tile boundaries move with the batch, so allow bf16 rounding noise only
             assert float((small - eager[pair]).abs().max()) < 5e-3, (pair, small, eager[pair])
+
+
+def test_swin_finetune_driver_cli(gpu, tmp_path):
+    """SURVEY section 8(f).4, the stand-alone SwinV2 fine-tune job (reference mvuld/main.py): `main.py --cfg ... --pretrained ...`
+    loads a reference-layout checkpoint, trains a few steps on the plumbing geometry, validates (P / R / F1 / PR-AUC), writes the
+    best-F1 checkpoint; `--eval` and `--throughput` (50 + 30 forwards, main.py:438-455) run the same model."""
+    from mvuld_amd import main as swin_main
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    pre = SwinTransformerV2(img_size=224, embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32], window_size=14, num_classes=1000,
+                            pretrained_window_sizes=[12, 12, 12, 6])
+    pth = str(tmp_path / "pre.pth")
+    torch.save({"model": pre.state_dict()}, pth)
+    out = str(tmp_path / "out")
+    common = ["--cfg", cfg, "--batch-size", "2", "--output", out, "--pretrained", pth,
+              "--opts", "TRAIN.EPOCHS", "1", "FUSED.SYNTH_TRAIN", "8", "FUSED.SYNTH_VAL", "4", "FUSED.SYNTH_TEST", "4", "TRAIN.AUTO_RESUME", "False"]
+    model = swin_main.main(common + ["--max-steps", "3"])
+    assert bool(torch.isfinite(model._mv_store.flat).all())
+    assert float(model.patch_embed.proj.weight.detach().float().cpu().sub(pre.patch_embed.proj.weight.detach()).abs().max()) < 1e-2   # started from the file
+    res = swin_main.main(common + ["--eval"])
+    assert len(res) == 4 and all(np.isfinite(v) for v in res)
+    tput = swin_main.main(common + ["--throughput"])
+    assert tput > 0
