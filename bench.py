@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="train mode: skip the extra batch-256 hipGraph inference leg")
+    ap.add_argument("--graph", action="store_true", help="train mode, N=1: replay the step as ONE captured hipGraph (mvuld_amd/graph_step.py) "
+                    "instead of enqueueing it from Python; off by default: on ROCm 7.2 a replay of the ~1900-node, 3-stream graph costs "
+                    "~21 us of host time per node and runs ~12 %% slower than the eager step (measured, DESIGN.md)")
     ap.add_argument("--infer-batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="functions per step of the CPU baseline (BASELINE.md section 4: batch 4)")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="stop the CPU baseline's timed runs once this much time is spent")
@@ -138,13 +141,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # --graph (N = 1): the whole step (forward, CE, backward on three streams, clip, AdamW, weight-copy refresh) captured once in a
+    # hipGraph and replayed; learning rate / Adam bias corrections / RNG step counter live in device memory (mvuld_amd/graph_step.py).
+    # Default: the step is enqueued from Python, kernel by kernel (faster on this ROCm release, see --graph's help).
+    graphed, graph_note = None, "eager (kernel-by-kernel enqueue from Python)"
+    if world_size() == 1 and args.graph:
+        try:
+            from mvuld_amd.graph_step import GraphedTrainStep
+            from mvuld_amd.models.unixcoder import RobertaModel
+            plan = RobertaModel.pack_plan(lens, device, ids.shape[1])      # fixed packing plan of the static batch
+            graphed = GraphedTrainStep(model, opt, sched, cross_entropy, (g, images, ids), labels, config.TRAIN.CLIP_GRAD,
+                                       model_kwargs={"seq_lens": plan})
+            it[0] = graphed.it
+            graph_note = "hipGraph replay (captured fwd+CE+bwd+clip+AdamW, 3 streams)"
+        except Exception as e:                                     # never lose the headline to a capture problem
+            graphed, graph_note = None, f"eager (graph capture failed: {e!r})"
+            from mvuld_amd import ops as _ops
+            _ops.RNG_OFFSET[0] = None
+            opt.dev_hyper = None
+            model.max_steps_in_flight = 2
+            torch.cuda.synchronize()
+    run = (lambda: graphed.step()[0]) if graphed is not None else step
+
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # host enqueue time per step (the GPU runs behind it)
+        loss = run()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3        # host time per step (the GPU runs behind it)
     fence()
     dt = time.perf_counter() - t0
     if world_size() > 1:
@@ -156,7 +181,10 @@ def main():
     value = n_fn / dt
     ms_per_step = dt / args.steps * 1e3
 
-    # host cost of enqueueing one step, with the two-steps-in-flight throttle off (3 steps queue up behind the GPU)
+    if graphed is not None:
+        it[0] = graphed.it
+        graphed.close()
+    # host cost of enqueueing one step from Python, with the two-steps-in-flight throttle off (3 steps queue up behind the GPU)
     fence()
     model.max_steps_in_flight = 0
     t0 = time.perf_counter()
@@ -201,7 +229,9 @@ def main():
                        "algorithmic_tflop_per_step_per_gpu": round(fl * args.batch / 1e12, 2),
                        "achieved_tflops_per_gpu": round(fl * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
                        "frac_of_dense_bf16_peak": round(fl * args.batch / (ms_per_step * 1e-3) / PEAK_BF16, 4),
-                       "host_loop_ms_per_step": round(host_ms, 2), "host_enqueue_ms_per_step": round(host_unthrottled_ms, 2),
+                       "step_launch": graph_note,
+                       "host_enqueue_ms_per_step": round(host_ms if graphed is not None else host_unthrottled_ms, 3),
+                       "host_enqueue_eager_ms_per_step": round(host_unthrottled_ms, 2),
                        "text_tokens_nonpad_frac": round(float(lens.sum()) / ids.numel(), 4), "final_loss": round(loss_val, 5)},
             "roofline": roofline, "cpu_baseline": cpu, "inference": inference,
         }

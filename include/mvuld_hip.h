@@ -133,13 +133,15 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
  * (<= B*nW*H*2 of them), summed by a second kernel; without it every workgroup adds its table with device atomics. */
 int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
-                        void* out, float* lse, float attn_drop_p, uint64_t drop_seed, int dtype, mvuld_stream_t stream);
+                        void* out, float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype,
+                        mvuld_stream_t stream);
 int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, int nW, int ws);   /* size of `ws_part` */
 int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                         float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes,
-                        int passes, float attn_drop_p, uint64_t drop_seed, int dtype, mvuld_stream_t stream);
+                        int passes, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype,
+                        mvuld_stream_t stream);
 /* passes: 1 = delta + dQ + dK/dV, 2 = bias-table gradient (mode 0; reads ws_delta / ws_qt written by pass 1), 3 = both.
  * The bias-table gradient feeds nothing else in backward, so a caller may issue pass 2 later, on another stream. */
 
@@ -160,7 +162,8 @@ int mvuld_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t n, m
 int mvuld_add(const void* a, const void* b, void* y, int64_t n, int dtype, mvuld_stream_t stream);
 /* y = x * keep / (1-p), keep = hash(seed, index) >= p: nn.Dropout of GraphModel.py:171-177, GATConv feat_drop,
  * RoBERTa hidden dropout; the same call with the same seed is the backward */
-int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, mvuld_stream_t stream);
+int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_offset, int dtype,
+                  mvuld_stream_t stream);
 
 /* fp32 -> [hi | lo | hi] (mode 0) or [hi | hi | lo] (mode 1) bf16 rows of width 3*Kp: feeding both to mvuld_gemm_nt with K = 3*Kp
  * gives a near-fp32 product (error ~2^-16) at matrix-core speed; used for the head's fp32 tail (Rs_GCN.py:57-70, GraphModel.py:201-209) */
@@ -179,7 +182,12 @@ int mvuld_embed_bwd(const int64_t* ids, const int* pos, const void* dy, float* d
 
 /* DropPath factors of a whole forward in one launch: out[k*B + b] = keep(seed, k, b) / (1 - rates[k]) (timm DropPath semantics,
  * swin_transformer_v2.py:301,304); rates [nblk] fp32 on the device (< 1), counter-based hash, no host RNG or copy. */
-int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, mvuld_stream_t stream);
+int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, const uint64_t* seed_offset,
+                          mvuld_stream_t stream);
+/* `seed_offset` (optional, here and in mvuld_dropout / mvuld_attn_*_mfma): one uint64 in DEVICE memory mixed into the host seed --
+ * the step counter of a hipGraph-captured training step (host seeds are frozen into the captured kernel arguments; the counter is
+ * advanced by mvuld_counter_add inside the graph, so every replay draws fresh masks).  NULL = host seed only. */
+int mvuld_counter_add(uint64_t* counter, uint64_t inc, mvuld_stream_t stream);
 
 /* y[i] = x[i] * s[0], s one fp32 on the device: upstream gradient of the scalar loss applied to dlogits (autograd of
  * CrossEntropyLoss when the loss is scaled or summed with other terms, main_bigvul.py:331-333) */
@@ -233,8 +241,12 @@ int mvuld_segment_pad_bwd(const void* dout, const int* node_offsets, void* dh, i
 int mvuld_sumsq(const float* x, int64_t n, float* partials, float* out, mvuld_stream_t stream);
 int mvuld_clip_coef(const float* sumsq, float max_norm, float grad_scale, float* norm_out, mvuld_stream_t stream);
 int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2,
-                float eps, float weight_decay, int step, const float* coef, int zero_grad, mvuld_stream_t stream);
-/* zero_grad != 0: the kernel also clears g after consuming it (replaces optimizer.zero_grad()'s separate pass). */
+                float eps, float weight_decay, int step, const float* coef, int zero_grad, const float* dev_hyper,
+                mvuld_stream_t stream);
+/* zero_grad != 0: the kernel also clears g after consuming it (replaces optimizer.zero_grad()'s separate pass).
+ * dev_hyper (optional, 3 floats on the device): {lr, 1 - beta1^step, sqrt(1 - beta2^step)} read by the kernel INSTEAD of lr / step --
+ * the per-iteration cosine learning rate and the bias corrections of a hipGraph-captured step, refreshed by a small copy before
+ * each replay. */
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,11 @@ struct AttnGeom {
     // probabilities scaled by inv = 1/(1-p); thr = 0 switches it off.  Counter-based: the backward passes regenerate the mask.
     unsigned drop_thr, drop_seed;
     float drop_inv;
+    const uint64_t* drop_off;   // optional device-resident step counter mixed into the seed (hipGraph replays draw fresh masks)
 };
+__device__ __forceinline__ unsigned am_seed(const AttnGeom& g) {
+    return g.drop_off ? g.drop_seed ^ (unsigned)(g.drop_off[0] * 0x9E3779B97F4A7C15ULL >> 32) : g.drop_seed;
+}
 __device__ __forceinline__ bool am_keep(unsigned elem, unsigned seed, unsigned thr) {
     unsigned x = elem ^ seed;
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
     const bool drop = MODE == 1 && g.drop_thr != 0;
+    const unsigned dseed = drop ? am_seed(g) : 0u;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
@@ -328,9 +333,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
         if (MODE == 1 && drop) {
             const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;           // element (b, h, q, k) -> 32-bit counter
             for (; kb < nfull64; kb += 64)
-                am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
             for (; kb < Np; kb += 32)
-                am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
         } else if (g4) {
             for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
             for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
@@ -438,6 +443,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
     const bool drop = MODE == 1 && g.drop_thr != 0;
+    const unsigned dseed = drop ? am_seed(g) : 0u;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
@@ -500,9 +506,9 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         if (MODE == 1 && drop) {
             const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;
             for (; kb < nfull64; kb += 64)
-                am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
             for (; kb < Np; kb += 32)
-                am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
         } else if (g4) {
             for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
             for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
@@ -846,6 +852,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
     const bool drop = MODE == 1 && g.drop_thr != 0;
+    const unsigned dseed = drop ? am_seed(g) : 0u;
     int C0 = 0;
     float qmul = g.scale;
     if (MODE == 0) {
@@ -906,9 +913,9 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         if (MODE == 1 && drop) {
             const unsigned eb = (unsigned)lse0 * NL + (unsigned)nkc;             // (b, h) row block + this lane's key; + q * NL per query
             for (; qb < nfull64; qb += 64)
-                am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
             for (; qb < Np; qb += 32)
-                am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, g.drop_seed, g.drop_thr, g.drop_inv);
+                am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
         } else if (g4) {
             for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
             for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
@@ -1016,8 +1023,8 @@ static int am_split(int64_t groups, int ntile) {
         else AM_LAUNCH(KERNEL, 64, 1, bytes, __VA_ARGS__);                            \
     } while (0)
 
-static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed) {
-    g.drop_thr = 0; g.drop_seed = 0; g.drop_inv = 1.f;
+static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed, const uint64_t* seed_offset) {
+    g.drop_thr = 0; g.drop_seed = 0; g.drop_inv = 1.f; g.drop_off = seed_offset;
     if (mode >= 1 && p > 0.f) {
         g.drop_thr = (unsigned)((double)p * 4294967296.0);
         g.drop_seed = (unsigned)(seed ^ (seed >> 32));
@@ -1027,13 +1034,13 @@ static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed) {
 
 extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid, void* out,
-                                   float* lse, float attn_drop_p, uint64_t drop_seed, int dtype, hipStream_t stream) {
+                                   float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
     if (am_check("attn_fwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_fwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && lse && (mode >= 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_fwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f};
-    am_set_dropout(g, mode, attn_drop_p, drop_seed);
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
+    am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
@@ -1069,15 +1076,15 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                                    float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int passes,
-                                   float attn_drop_p, uint64_t drop_seed, int dtype, hipStream_t stream) {
+                                   float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(passes >= 1 && passes <= 3, "attn_bwd_mfma: passes is a mask of 1 (delta + dQ + dK/dV) and 2 (bias-table gradient)");
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && dout && lse && dqkv && ws_delta, "attn_bwd_mfma: null pointer");
     MV_CHECK_ARG(mode >= 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_bwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
-    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f};
-    am_set_dropout(g, mode, attn_drop_p, drop_seed);
+    AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
+    am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     int64_t ntok = (int64_t)B * nW * N;
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }
     const int Npad = (N + 31) / 32 * 32;

@@ -202,8 +202,11 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     return (uint32_t)x;
 }
 // y = x * keep(i) / (1-p), keep(i) = hash(seed, i) >= p.  Same call on the gradient in backward.
+// seed_off (optional): one uint64 on the device added to the host seed -- a step counter that lives in device memory, so that a
+// hipGraph replay of a captured training step draws fresh masks (the host seed is frozen into the captured kernel arguments).
 template <typename T>
-__global__ void dropout_k(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed) {
+__global__ void dropout_k(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, uint64_t seed, const uint64_t* __restrict__ seed_off) {
+    if (seed_off) seed += seed_off[0] * 0xD1B54A32D192ED03ULL;
     const float inv = 1.0f / (1.0f - p);
     const uint32_t thr = (uint32_t)(p * 4294967296.0);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -212,7 +215,9 @@ __global__ void dropout_k(const T* __restrict__ x, T* __restrict__ y, int64_t n,
     }
 }
 // the same mask, eight bf16 per lane through 16-byte accesses (n % 8 == 0, 16-byte aligned): the text encoder's hidden dropouts
-__global__ void dropout_bf16x8_k(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n8, float p, uint64_t seed) {
+__global__ void dropout_bf16x8_k(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n8, float p, uint64_t seed,
+                                 const uint64_t* __restrict__ seed_off) {
+    if (seed_off) seed += seed_off[0] * 0xD1B54A32D192ED03ULL;
     const float inv = 1.0f / (1.0f - p);
     const uint32_t thr = (uint32_t)(p * 4294967296.0);
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
@@ -225,14 +230,14 @@ __global__ void dropout_bf16x8_k(const bf16* __restrict__ x, bf16* __restrict__ 
         *(bf16x8*)(y + c * 8) = v;
     }
 }
-extern "C" int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, hipStream_t stream) {
+extern "C" int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
     MV_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
     if (dtype == MVULD_BF16 && n % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
         const int grid = (int)min((int64_t)8192, cdiv(n / 8, 256));
-        hipLaunchKernelGGL(dropout_bf16x8_k, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8, p, seed);
+        hipLaunchKernelGGL(dropout_bf16x8_k, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n / 8, p, seed, seed_offset);
     } else {
         const int grid = (int)min((int64_t)8192, cdiv(n, 256));
-        DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n, p, seed));
+        DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)x, (T*)y, n, p, seed, seed_offset));
     }
     MV_LAUNCH_CHECK("dropout");
     return 0;
@@ -745,17 +750,28 @@ extern "C" int mvuld_scale_by_dev(const float* x, const float* s, float* y, int6
 // DropPath (stochastic depth, timm semantics: swin_transformer_v2.py:301,304 via timm.models.layers.DropPath): per (block, sample)
 // keep / (1 - rate) factors drawn on the device from the counter hash -- out[k*B + b] = hash(seed, k*B + b) >= rate[k] ? 1/(1-rate[k]) : 0.
 // No host RNG, no host -> device copy in the step.
-__global__ void droppath_scales_k(const float* __restrict__ rates, float* __restrict__ out, int nblk, int B, uint64_t seed) {
+__global__ void droppath_scales_k(const float* __restrict__ rates, float* __restrict__ out, int nblk, int B, uint64_t seed,
+                                  const uint64_t* __restrict__ seed_off) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblk * B) return;
+    if (seed_off) seed += seed_off[0] * 0xD1B54A32D192ED03ULL;
     const float p = rates[i / B];
     const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
     const bool keep = mix32(seed + (uint64_t)i * 0x9E3779B97F4A7C15ULL) >= thr;
     out[i] = keep ? 1.0f / (1.0f - p) : 0.f;
 }
-extern "C" int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, hipStream_t stream) {
+extern "C" int mvuld_droppath_scales(const float* rates, float* out, int nblk, int B, uint64_t seed, const uint64_t* seed_offset, hipStream_t stream) {
     MV_CHECK_ARG(rates && out && nblk > 0 && B > 0, "droppath_scales: bad args");
-    hipLaunchKernelGGL(droppath_scales_k, dim3((unsigned)cdiv((int64_t)nblk * B, 256)), dim3(256), 0, stream, rates, out, nblk, B, seed);
+    hipLaunchKernelGGL(droppath_scales_k, dim3((unsigned)cdiv((int64_t)nblk * B, 256)), dim3(256), 0, stream, rates, out, nblk, B, seed, seed_offset);
     MV_LAUNCH_CHECK("droppath_scales");
+    return 0;
+}
+
+// p[0] += inc  (the device-resident step counter behind `seed_offset`: one launch per training step, inside the captured graph)
+__global__ void counter_add_k(uint64_t* p, uint64_t inc) { p[0] += inc; }
+extern "C" int mvuld_counter_add(uint64_t* counter, uint64_t inc, hipStream_t stream) {
+    MV_CHECK_ARG(counter, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_k, dim3(1), dim3(1), 0, stream, counter, inc);
+    MV_LAUNCH_CHECK("counter_add");
     return 0;
 }

@@ -14,7 +14,9 @@
 //     partial in register order (1 KiB per store instruction) and a second, fully parallel kernel adds the partials into dW.
 //     (fp32 atomics straight from the accumulators would be 256 KiB per workgroup at ~50 ns per 256 bytes and CU: as long as
 //     the main loop itself.)
-// M % 32 == 0 (token counts of the model are), N % 8 == 0, K % 8 == 0; column tails are computed on clamped addresses and dropped.
+// N % 8 == 0, K % 8 == 0; column tails are computed on clamped addresses and dropped.  Any M: the LDS-DMA goes through buffer
+// descriptors sized to the M valid rows, so the rows of the last 32-token slab beyond M read as zeros (out-of-range buffer loads
+// return 0) and add nothing -- the pad-free text encoder hands over token counts that are multiples of nothing.
 #include "gemm_common.h"
 
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
@@ -41,31 +43,33 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
     const int tl = blockIdx.x / nsplit, ks = blockIdx.x % nsplit;
     const int tn = tl / tiles_k, tk = tl % tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
-    const int mslabs = M / 32;
+    const int mslabs = (M + 31) / 32;
     const int s0 = ks * per, s1 = min(mslabs, s0 + per);
     const int nk = s1 - s0;                              // >= 1 by construction of nsplit / per on the host
 
     // LDS-DMA map: one instruction = 1 KiB = 2 image rows; lane l -> row l >> 5, slot l & 31, fetching chunk slot ^ 2(row & 7).
     // Wave w issues pieces 2w, 2w+1 (rows 4w .. 4w+3) of the dY image and of the X image.
-    const bf16* ga[2];
-    const bf16* gb[2];
+    // byte offsets into the two buffers (< 4 GiB each, checked on the host); rows >= M fall outside the descriptors and load zeros
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, (int)min((int64_t)M * ldy * 2, (int64_t)0x7fffffff), 0x00020000);
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)min((int64_t)M * ldx * 2, (int64_t)0x7fffffff), 0x00020000);
+    unsigned va[2], vb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 2 + (lane >> 5);
         const int ch = (lane & 31) ^ (2 * (r & 7));
         const int ca = n0 + ch * 8, cb = k0 + ch * 8;
-        ga[i] = dY + (int64_t)(s0 * 32 + r) * ldy + (ca < N ? ca : 0);
-        gb[i] = X + (int64_t)(s0 * 32 + r) * ldx + (cb < K ? cb : 0);
+        va[i] = (unsigned)(((int64_t)(s0 * 32 + r) * ldy + (ca < N ? ca : 0)) * 2);
+        vb[i] = (unsigned)(((int64_t)(s0 * 32 + r) * ldx + (cb < K ? cb : 0)) * 2);
     }
-    const int64_t stepa = 32 * ldy, stepb = 32 * ldx;
+    const unsigned stepa = (unsigned)(64 * ldy), stepb = (unsigned)(64 * ldx);      // bytes per 32-row slab
     int issued = 0;
     auto issue_one = [&]() {
         if (issued < nk) {
             char* st = smem + (issued & 3) * T_STAGE_BYTES;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((glb_vp)(ga[i] + issued * stepa), (lds_vp)(st + (wave * 2 + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_vp)(gb[i] + issued * stepb), (lds_vp)(st + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_vp)(st + (wave * 2 + i) * 1024), 16, va[i], issued * stepa, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(st + 16384 + (wave * 2 + i) * 1024), 16, vb[i], issued * stepb, 0, 0);
             }
             ++issued;
         }
@@ -190,14 +194,14 @@ static int tn256_num_cus() {
 static void tn256_plan(int M, int N, int K, int& nsplit, int& per) {
     nsplit = 0;
     per = 0;
-    if (M % 32 != 0 || M < 256) return;
+    if (M < 256) return;
     const int64_t tiles = cdiv(N, 256) * cdiv(K, 256);
     // fewer than 8 tiles would mean > 32 splits: the partial slabs (256 KiB each) then cost more than the 128 x 128 kernel's atomics
     // (measured, tools/gemm_shapes.py: 512 x 512 and 256 x 256 weights lose, 768 x 768 breaks even, everything wider wins 15-25 %)
     if (tiles < 8) return;
     // most of every tile must be real weight: (padded area) <= 1.25 x (N x K)
     if (cdiv(N, 256) * 256 * cdiv(K, 256) * 256 * 4 > (int64_t)N * K * 5) return;
-    const int mslabs = M / 32;
+    const int mslabs = (M + 31) / 32;
     int want = (int)(tn256_num_cus() / tiles);
     if (want < 1) want = 1;
     if (want > mslabs / 8) want = mslabs / 8 > 0 ? mslabs / 8 : 1;      // at least 8 ring steps per split
@@ -218,6 +222,7 @@ int mvuld_gemm_tn256_try(const void* dY, int64_t ldy, const void* X, int64_t ldx
     int nsplit, per;
     tn256_plan(M, N, K, nsplit, per);
     if (nsplit < 1) return -1;
+    if ((int64_t)M * ldy * 2 >= (int64_t)0x7fffffff || (int64_t)M * ldx * 2 >= (int64_t)0x7fffffff) return -1;     // 32-bit buffer offsets
     const int64_t need = mvuld_gemm_tn256_workspace_bytes(M, N, K);
     if (nsplit > 1 && (!ws || ws_bytes < need || (((uintptr_t)ws) & 15) != 0)) return -1;
     static const bool attr = [] {

@@ -41,7 +41,9 @@ __global__ void clip_coef_k(const float* __restrict__ sumsq, float max_norm, flo
 // which replaces the separate zero_grad() fill pass over the 0.9 GB buffer.
 __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                bf16* __restrict__ p16, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                                               float bc1, float bc2_sqrt, const float* __restrict__ coef, int zero_grad) {
+                                               float bc1, float bc2_sqrt, const float* __restrict__ coef, int zero_grad,
+                                               const float* __restrict__ dev_hyper) {
+    if (dev_hyper) { lr = dev_hyper[0]; bc1 = dev_hyper[1]; bc2_sqrt = dev_hyper[2]; }      // per-step values from device memory (captured step)
     const float c = coef ? coef[1] : 1.0f;
     const float step = lr / bc1;
     const float decay = 1.0f - lr * wd;
@@ -96,13 +98,13 @@ extern "C" int mvuld_clip_coef(const float* sumsq, float max_norm, float grad_sc
     return 0;
 }
 extern "C" int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int step, const float* coef, int zero_grad, hipStream_t stream) {
+                           float weight_decay, int step, const float* coef, int zero_grad, const float* dev_hyper, hipStream_t stream) {
     MV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
     MV_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p16) & 7) == 0, "adamw: buffers must be 16-byte aligned");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     const int grid = (int)min((int64_t)8192, cdiv(n, 1024));
-    hipLaunchKernelGGL(adamw_k, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, coef, zero_grad);
+    hipLaunchKernelGGL(adamw_k, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, coef, zero_grad, dev_hyper);
     MV_LAUNCH_CHECK("adamw");
     return 0;
 }

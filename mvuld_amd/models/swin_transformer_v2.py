@@ -409,7 +409,7 @@ class SwinTransformerV2(nn.Module):
             self._dp_rates = torch.tensor(rates, dtype=torch.float32).to(device)
         self._dp_seed = (self._dp_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         out = torch.empty((len(rates), B), dtype=torch.float32, device=device)
-        call("droppath_scales", ptr(self._dp_rates), ptr(out), len(rates), B, self._dp_seed)
+        call("droppath_scales", ptr(self._dp_rates), ptr(out), len(rates), B, self._dp_seed, ops.rng_offset_ptr())
         return out
 
     def forward_features(self, x):

@@ -382,11 +382,20 @@ def add(a, b):
     return y
 
 
+# Device-resident step counter (int64 [1]) mixed into every RNG kernel's seed, or None.  A hipGraph-captured training step sets it
+# (graph_step.GraphedTrainStep): host seeds are frozen into the captured launches, the counter advances inside the graph.
+RNG_OFFSET = [None]
+
+
+def rng_offset_ptr():
+    return ptr(RNG_OFFSET[0])
+
+
 def dropout(x, p, seed):
     if p <= 0.0:
         return x
     y = torch.empty_like(x)
-    call("dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, dt(x))
+    call("dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, rng_offset_ptr(), dt(x))
     return y
 
 
@@ -427,7 +436,8 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
         raise RuntimeError("packed (mode 2) attention exists on the matrix-core path only (bf16)")
     hip.TIMING.annotate(name, 4.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
     if name == "attn_fwd_mfma":
-        call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), g.drop_p, g.drop_seed, dt(qkv))
+        call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), g.drop_p, g.drop_seed,
+             rng_offset_ptr(), dt(qkv))
     else:
         if g.drop_p > 0.0:
             raise RuntimeError("attention-probability dropout exists on the matrix-core attention path only (bf16)")
@@ -450,11 +460,12 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         wg = wgrad_stream_for_current() if g.mode == 0 else None
         if g.mode != 0 or wg is None:
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
-            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed, dt(qkv))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed,
+                 rng_offset_ptr(), dt(qkv))
             return dqkv
         # The bias-table gradient feeds nothing else in backward: dQ / dK / dV stay on this stream, the table pass (and whatever
         # the caller does with dtable16 afterwards: see bias_stream) goes to the weight-gradient stream.
-        call("attn_bwd_mfma", *args, None, 0, 1, 0.0, 0, dt(qkv))
+        call("attn_bwd_mfma", *args, None, 0, 1, 0.0, 0, None, dt(qkv))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(qkv.device))
         wg.wait_event(ev)
@@ -462,7 +473,7 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
             t.record_stream(wg)
         with torch.cuda.stream(wg):
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))
-            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, 0.0, 0, dt(qkv))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, 0.0, 0, None, dt(qkv))
         BIAS_STREAM[0] = wg
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)

@@ -116,6 +116,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(param_groups, defaults)
         self._step = 0
         self._clipped = False
+        self.dev_hyper = None        # fp32 [n_groups, 3] on the device: {lr, 1-b1^t, sqrt(1-b2^t)} per group, read by the kernel when set
 
     def clip_grad_norm_(self, max_norm):
         self._clipped = True
@@ -134,17 +135,27 @@ class FusedAdamW(torch.optim.Optimizer):
             # reach the kernel -- through the same coefficient, with clipping off
             self.clip_grad_norm_(0.0)
         coef = st.norm if self._clipped else None
-        for (a, b), grp in zip(st.group_ranges, self.param_groups):
+        for gi, ((a, b), grp) in enumerate(zip(st.group_ranges, self.param_groups)):
             if b <= a:
                 continue
             b1, b2 = grp["betas"]
+            hyper = None if self.dev_hyper is None else self.dev_hyper.data_ptr() + 12 * gi
             call("adamw", st.flat.data_ptr() + 4 * a, st.grad.data_ptr() + 4 * a, st.exp_avg.data_ptr() + 4 * a,
                  st.exp_avg_sq.data_ptr() + 4 * a, st.flat16.data_ptr() + 2 * a, b - a, float(grp["lr"]), float(b1), float(b2),
-                 float(grp["eps"]), float(grp["weight_decay"]), self._step, ptr(coef), 1)
+                 float(grp["eps"]), float(grp["weight_decay"]), self._step, ptr(coef), 1, hyper)
         st.grads_zeroed = True            # the kernel cleared every gradient it consumed: the zero_grad() after this step is free
         self._clipped = False
         ops.bump_weight_epoch()           # transposed weight copies are stale now: refresh the registered ones together
         ops.refresh_store_transposes(st)
+
+    def host_hyper(self):
+        """[n_groups, 3] {lr, 1 - b1^t, sqrt(1 - b2^t)} for the NEXT step() (t = steps taken + 1): what dev_hyper must hold before it."""
+        t = self._step + 1
+        rows = []
+        for grp in self.param_groups:
+            b1, b2 = grp["betas"]
+            rows.append([float(grp["lr"]), 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5])
+        return torch.tensor(rows, dtype=torch.float32)
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grad()

@@ -521,7 +521,7 @@ def test_embed_im2col_patchmerge_dropout(gpu, dtype):
 
 @pytest.mark.parametrize("mode", ["tn256", "slab128", "atomic"])
 @pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (1000, 384, 136), (777, 72, 200), (20000, 256, 512), (16384, 776, 392),
-                                   (16384, 768, 768), (6272, 1000, 760), (25088, 512, 2048), (2048, 256, 256)])
+                                   (16384, 768, 768), (6272, 1000, 760), (25088, 512, 2048), (2048, 256, 256), (9917, 768, 3072), (1001, 1024, 520)])
 def test_gemm_tn_wgrad(gpu, M, N, K, mode):
     """dW += dY^T X and db += colsum(dY) through the transpose-free matrix-core kernels (bf16 operands).  Three ways of combining the
     split token contraction: "tn256" = the 256 x 256-tile LDS-DMA kernel with slab partials + reduction launch where the shape

@@ -880,3 +880,59 @@ def test_swin_finetune_driver_cli(gpu, tmp_path):
     assert len(res) == 4 and all(np.isfinite(v) for v in res)
     tput = swin_main.main(common + ["--throughput"])
     assert tput > 0
+
+
+def test_graphed_train_step_matches_eager(gpu):
+    """The hipGraph-captured training step (graph_step.GraphedTrainStep: forward, CE, backward on the three streams, clip, fused AdamW
+    with learning rate / bias corrections read from device memory, RNG step counter advanced inside the graph) against the same
+    steps enqueued from Python: same model, same data, same cosine schedule, dropouts off -> the parameters after 4 steps must agree
+    to fp32-atomic-order noise, and the loss sequence must match."""
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.graph_step import GraphedTrainStep
+    from mvuld_amd.lr_scheduler import build_scheduler
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    config = _tiny_config(torch.bfloat16)
+    f = config.FUSED
+    g, images, ids, labels = synthetic.make_batch([3, 4, 5, 6], config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    lens = (ids != 1).sum(1)
+    g.index()
+    g, images, ids, labels = g.to(gpu), images.to(gpu), ids.to(gpu), labels.to(gpu)
+
+    def make():
+        torch.manual_seed(7)
+        m = build_fused_model(config)
+        load_synth_into(m)
+        m = m.to(gpu).train()
+        m.head.p_gat = m.head.p_mlp = m.head.p_hidden = 0.0
+        m.head.gat.feat_drop_p = m.head.gat2.feat_drop_p = 0.0
+        o = build_optimizer(config, m)
+        return m, o, build_scheduler(config, o, 10)
+    n_steps = 3 + 4                          # GraphedTrainStep runs 3 eager warm-up steps before capturing
+    m1, o1, s1 = make()
+    losses_e = []
+    for it in range(n_steps):
+        s1.step_update(it)
+        lg = m1(g, images, ids, seq_lens=lens)
+        loss, _ = cross_entropy(lg, labels)
+        loss.backward()
+        o1.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
+        o1.step()
+        o1.zero_grad()
+        losses_e.append(float(loss.detach()))
+    m2, o2, s2 = make()
+    from mvuld_amd.models.unixcoder import RobertaModel
+    gs = GraphedTrainStep(m2, o2, s2, cross_entropy, (g, images, ids), labels, config.TRAIN.CLIP_GRAD,
+                          model_kwargs={"seq_lens": RobertaModel.pack_plan(lens, gpu, ids.shape[1])})
+    losses_g = []
+    for _ in range(4):
+        loss, norm = gs.step()
+        losses_g.append(float(loss))
+    gs.close()
+    assert o2._step == o1._step == n_steps
+    print("eager losses", losses_e[3:], "graph losses", losses_g)
+    for a, b in zip(losses_e[3:], losses_g):
+        assert abs(a - b) < 2e-2 * max(1.0, abs(a))
+    p1, p2 = m1._mv_store.flat, m2._mv_store.flat
+    assert float((p1 - p2).norm() / p1.norm()) < 2e-3
