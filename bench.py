@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="functions per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 = BASELINE configs[4]: bf16 step with the encoders' forward QKV / FFN GEMMs in e4m3")
     ap.add_argument("--cfg", default=CFG)
     ap.add_argument("--opts", nargs="+", default=None)
     ap.add_argument("--mode", default="train", choices=["train", "infer"],

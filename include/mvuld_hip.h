@@ -48,6 +48,26 @@ int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, in
  * (K % 32 == 0, >= 128 tiles, plain store) take it; 0 (default) = never.  No stream argument: host-side setting. */
 int mvuld_set_gemm_256_min_k(int min_k);
 
+/* fp8 forward GEMMs (BASELINE configs[4]: "fp8 (CDNA4 MFMA) QKV/FFN GEMMs in SwinV2 + UniXcoder"; same call sites as mvuld_gemm_nt:
+ * swin_transformer_v2.py:146-152,177,26-32 and the RobertaModel dense layers behind unixcoder.py:36).
+ * mvuld_quant_e4m3: per-tensor quantisation to OCP e4m3 (gfx950's native fp8): scale_out[0] = max|x| / 448, out = e4m3(x / scale);
+ *   n % 8 == 0; `partials` = 1024 floats of scratch.
+ * mvuld_gemm_nt_fp8: C[M,N] (bf16) = epi(scale_a[0] * scale_b[0] * A8[M,K] . B8[N,K]^T + bias) on v_mfma_f32_16x16x32_fp8_fp8 with fp32
+ *   accumulation (the persistent 256 x 256 kernel; K % 64 == 0, K >= 256, N % 8 == 0, lda / ldb multiples of 16); epilogue NONE / BIAS /
+ *   GELU (+ pre-activation to `aux`).  With the GELU epilogue the activation can leave as e4m3 for the next product without a pass of
+ *   its own: q_out[M,N] (row stride ldq bytes) = e4m3(bf16(gelu) / q_state[0]); max|gelu| is folded into q_state[1] (atomic max on the
+ *   float's bits) for the NEXT step's scale ("delayed scaling": mvuld_fp8_roll_scales); C may then be null (inference: fp8 only).
+ * mvuld_layernorm_fwd_q8: mvuld_layernorm_fwd that also emits y as e4m3 under q_state[0] and folds max|y| into q_state[1].
+ * mvuld_fp8_roll_scales: for each of n {scale, amax} pairs: amax > 0 ? (scale = amax / 448, amax = 0) : unchanged. */
+int mvuld_quant_e4m3(const void* x, int64_t n, int dtype, void* out, float* scale_out, float* partials, mvuld_stream_t stream);
+int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                      const float* bias, int epilogue, void* aux, int64_t ldaux, const float* scale_a, const float* scale_b,
+                      void* q_out, int64_t ldq, float* q_state, mvuld_stream_t stream);
+int mvuld_layernorm_fwd_q8(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
+                           const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd, int64_t rows, int C, float eps,
+                           void* q_out, float* q_state, mvuld_stream_t stream);
+int mvuld_fp8_roll_scales(float* state, int n, mvuld_stream_t stream);
+
 /* Routing of mvuld_gemm_nt's bf16 -> bf16 plain-store products to the persistent 256 x 256-tile kernel (csrc/gemm_p256.hip):
  * 0 = never, 1 = default rule (>= 160 tiles, N % 128 == 0: the tall Linear layers of the two encoders, same call sites as
  * mvuld_gemm_nt), 2 = every legal shape (K % 32 == 0, K >= 128, N % 8 == 0, no ELU epilogues; tests and A/B timing).  Host-side setting, no stream. */

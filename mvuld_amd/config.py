@@ -159,7 +159,7 @@ _DEFAULTS = {
     # ---- additions of this implementation (absent in the reference; all optional) ----
     "FUSED": {
         "ENABLE": True,            # train the three encoders in one step (north_star); False = reference-faithful head-only step
-        "DTYPE": "bf16",           # activation storage: bf16 | fp32
+        "DTYPE": "bf16",           # activation storage: bf16 | fp32 | fp8 (= bf16 + forward encoder GEMMs in e4m3)
         "SYNTHETIC": True,         # synthetic Big-Vul-shaped data (there is no dataset on the box)
         "SYNTH_TRAIN": 256, "SYNTH_VAL": 64, "SYNTH_TEST": 64,
         "SEQ_LEN": 512, "NODES_LO": 150, "NODES_HI": 250,

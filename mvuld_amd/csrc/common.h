@@ -7,7 +7,7 @@
 
 typedef __bf16 bf16;
 
-enum { MVULD_F32 = 0, MVULD_BF16 = 1 };
+enum { MVULD_F32 = 0, MVULD_BF16 = 1, MVULD_FP8 = 2 };   // FP8 = OCP e4m3fn (gfx950's v_cvt_pk_fp8_f32 / fp8 MFMA format)
 
 // thread-local last error text (mvuld_last_error)
 void mvuld_set_error(const char* fmt, ...);
@@ -42,6 +42,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// saturate to the e4m3 range before v_cvt_pk_fp8_f32 (an out-of-range input converts to NaN, not to the largest value)
+__device__ __forceinline__ float q_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -775,3 +775,89 @@ extern "C" int mvuld_counter_add(uint64_t* counter, uint64_t inc, hipStream_t st
     MV_LAUNCH_CHECK("counter_add");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ fp8 (OCP e4m3) quantisation, per-tensor scale
+// scale = max|x| / 448 (the largest finite e4m3 value), q = round_to_e4m3(x / scale): the operands of the fp8 forward GEMMs
+// (BASELINE config 5: QKV / FFN GEMMs of the two encoders; swin_transformer_v2.py:146-152,177,26-32, HF RobertaModel dense layers).
+// Two launches: per-block |x| maxima (deterministic: no float atomics), then the conversion, which folds those maxima into `scale`
+// (v_cvt_pk_fp8_f32, eight values per lane, 16-byte loads and 8-byte stores).
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_k(const T* __restrict__ x, int64_t n, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(ldf(x + i)));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void absmax_bf16x8_k(const bf16* __restrict__ x, int64_t n8, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = *(const bf16x8*)(x + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v.v[e]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// every block folds the (<= 1024) per-block maxima itself (4 KB out of L2) instead of a third launch; block 0 publishes the scale
+template <typename T>
+__global__ __launch_bounds__(256) void quant_e4m3_k(const T* __restrict__ x, int64_t n8, const float* __restrict__ partials, int nblk,
+                                                    float* __restrict__ scale, uint2* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, partials[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float sc = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-12f) * (1.0f / 448.0f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = sc;
+    const float inv = 1.0f / sc;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
+        float f[8];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = *(const bf16x8*)(x + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v.v[e] * inv;
+        } else {
+            const float4 v0 = *(const float4*)(x + c * 8), v1 = *(const float4*)(x + c * 8 + 4);
+            f[0] = v0.x * inv; f[1] = v0.y * inv; f[2] = v0.z * inv; f[3] = v0.w * inv;
+            f[4] = v1.x * inv; f[5] = v1.y * inv; f[6] = v1.z * inv; f[7] = v1.w * inv;
+        }
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        out[c] = make_uint2(lo, hi);
+    }
+}
+extern "C" int mvuld_quant_e4m3(const void* x, int64_t n, int dtype, void* out, float* scale_out, float* partials, hipStream_t stream) {
+    MV_CHECK_ARG(x && out && scale_out && partials && n > 0 && n % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0,
+                 "quant_e4m3: bad args (n % 8 == 0, 16-byte aligned, 1024-float scratch)");
+    const int grid = (int)min((int64_t)1024, cdiv(n, 2048));
+    if (dtype == MVULD_BF16) hipLaunchKernelGGL(absmax_bf16x8_k, dim3(grid), dim3(256), 0, stream, (const bf16*)x, n / 8, partials);
+    else hipLaunchKernelGGL(absmax_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, n, partials);
+    const int grid2 = (int)min((int64_t)4096, cdiv(n / 8, 512));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(quant_e4m3_k<T>, dim3(grid2), dim3(256), 0, stream, (const T*)x, n / 8, partials, grid, scale_out, (uint2*)out));
+    MV_LAUNCH_CHECK("quant_e4m3");
+    return 0;
+}
+
+// delayed scaling: the {scale, amax} pairs the fused e4m3 emitters (layernorm_fwd_q8, the fp8 GEMM's GELU epilogue) read and fold into
+__global__ void fp8_roll_scales_k(float* __restrict__ state, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float amax = state[2 * i + 1];
+    if (amax > 0.f) { state[2 * i] = amax * (1.0f / 448.0f); state[2 * i + 1] = 0.f; }
+}
+extern "C" int mvuld_fp8_roll_scales(float* state, int n, hipStream_t stream) {
+    MV_CHECK_ARG(state && n > 0, "fp8_roll_scales: bad args");
+    hipLaunchKernelGGL(fp8_roll_scales_k, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, state, n);
+    MV_LAUNCH_CHECK("fp8_roll_scales");
+    return 0;
+}

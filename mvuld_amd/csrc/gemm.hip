@@ -1129,6 +1129,26 @@ extern "C" int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, i
     return 0;
 }
 
+// C = epi(scale_a * scale_b * A8 . B8^T + bias): OCP e4m3 operands (mvuld_quant_e4m3), fp32 accumulate, bf16 out
+extern "C" int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                                 const float* bias, int epilogue, void* aux, int64_t ldaux, const float* scale_a, const float* scale_b,
+                                 void* q_out, int64_t ldq, float* q_state, hipStream_t stream) {
+    MV_CHECK_ARG(A8 && B8 && (C || q_out) && M > 0 && N > 0 && K > 0, "gemm_nt_fp8: bad args");
+    MV_CHECK_ARG(!q_out || (q_state && epilogue == EPI_GELU), "gemm_nt_fp8: the e4m3 side output belongs to the GELU epilogue and needs its {scale, amax} pair");
+    MV_CHECK_ARG(epilogue == EPI_NONE || epilogue == EPI_BIAS || epilogue == EPI_GELU, "gemm_nt_fp8: epilogue %d (NONE / BIAS / GELU only)", epilogue);
+    GemmArgs g;
+    g.A = A8; g.B = B8; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = g.sB = g.sC = 0;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.splitk = 1; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.sAux = 0;
+    g.alpha = 1.0f; g.epi = epilogue; g.out_mode = OUT_STORE; g.scale_a = scale_a; g.scale_b = scale_b;
+    g.q_out = q_out; g.ldq = ldq; g.q_scale = q_state; g.q_amax = q_state ? (unsigned*)(q_state + 1) : nullptr;
+    if (mvuld_gemm_nt_p256_fp8(g, stream) != 0) {
+        mvuld_set_error("gemm_nt_fp8: shape M=%d N=%d K=%d not eligible (K %% 64 == 0, K >= 256, N %% 8 == 0, 16-byte aligned rows)", M, N, K);
+        return 1;
+    }
+    MV_LAUNCH_CHECK("gemm_nt_fp8");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static int g_k256 = -1;     // minimum K for the 256 x 256 ring kernel (0 = never); -1 = read MVULD_GEMM_256 on first use
 
@@ -1155,7 +1175,7 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.splitk = splitk; g.bias = bias; g.aux = aux; g.ldaux = ldaux;
-    g.sAux = strideAux; g.alpha = alpha; g.epi = epilogue; g.out_mode = out_mode;
+    g.sAux = strideAux; g.alpha = alpha; g.epi = epilogue; g.out_mode = out_mode; g.scale_a = nullptr; g.scale_b = nullptr;
     const bool aligned = (K % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (strideA % 8 == 0) && (strideB % 8 == 0) &&
                          (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const bool use_mfma = (dtype_in == MVULD_BF16) && aligned && !force_simple && (M >= 32) && (N >= 32);

@@ -12,6 +12,10 @@ struct GemmArgs {
     const float* bias;                     // [N] or null
     void* aux; int64_t ldaux, sAux;        // pre-activation (GELU out / dGELU in) or ELU output (dELU in); dtype of C
     float alpha; int epi; int out_mode;
+    const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (one fp32 each, on the device), or null
+    // fp8 GELU epilogue: also (or, with C == nullptr, only) emit the activation as e4m3 under the scale at q_scale[0], and fold
+    // max|value| into q_amax[0] (atomicMax on the bit pattern of a non-negative float) for the next step's scale
+    void* q_out = nullptr; int64_t ldq = 0; const float* q_scale = nullptr; unsigned* q_amax = nullptr;
 };
 
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
@@ -46,6 +50,8 @@ template <typename TO> __device__ __forceinline__ float dgelu_t(float x) {
 
 // persistent 256 x 256 NT kernel (gemm_p256.hip); returns 0 when it took the launch, -1 when the shape is not its to take
 int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream);
+// the same kernel on OCP e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8): 0 = launched, -1 = shape not eligible (K % 64, K >= 256, N % 8)
+int mvuld_gemm_nt_p256_fp8(const GemmArgs& g, hipStream_t stream);
 
 // 256 x 256-tile weight-gradient kernel (gemm_tn256.hip); `ws` = slab area (no ticket block); 0 = took the launch, -1 = not its shape
 int64_t mvuld_gemm_tn256_workspace_bytes(int M, int N, int K);

@@ -40,7 +40,11 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // NI = 16-row accumulator fragments per wave along M: the tile is (32 * NI) x 256, NI = 8 -> 256 x 256.  The host picks NI per
 // launch so that the tiles fill whole rounds of the persistent grid (a 25088 x 2048 product is 784 tiles of 256 rows = 3.06 rounds of
 // 256 workgroups, but 1256 tiles of 160 rows = 4.9 rounds of 0.67 the length).
-template <int EPI, int NI>
+// FP8: the operands are OCP e4m3 bytes.  A 64-byte LDS row then holds 64 k instead of 32, the DMA / swizzle / fragment-read byte
+// geometry is unchanged; a lane's 16-byte chunk feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: the same k subset
+// on both operands, so any split is a valid contraction order).  Half the L2 -> LDS bytes and LDS reads per FLOP.
+typedef long __attribute__((ext_vector_type(2))) i64x2_t;
+template <int EPI, int NI, bool FP8 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
@@ -52,11 +56,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     const int fr = lane & 15, fg = lane >> 4;
     const int nt = tiles_m * tiles_n;
     const int G = gridDim.x, bx = blockIdx.x;
-    const int nk = g.K / P_BK;
+    constexpr int ES = FP8 ? 1 : 2;                      // bytes per operand element; a k-step is always 64 bytes of every row
+    const int nk = g.K * ES / 64;
     const int my_tiles = bx < nt ? (nt - bx + G - 1) / G : 0;
     const int total = my_tiles * nk;
-    const bf16* A = (const bf16*)g.A;
-    const bf16* B = (const bf16*)g.B;
+    const char* A = (const char*)g.A;
+    const char* B = (const char*)g.B;
     bf16* C = (bf16*)g.C;
     bf16* aux = (bf16*)g.aux;
 
@@ -73,8 +78,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     // swizzle keeps in its slot.  The A tile is 2 * NI pieces: wave w issues piece w and, if it exists, piece w + 8; the B tile is
     // 16 pieces: wave w issues pieces 2w, 2w + 1.  So a wave has 3 or 4 operations per k-step in flight (the counted waits below).
     const bool a2 = wave + 8 < 2 * NI;                   // wave-uniform
-    const bf16* ga[2];
-    const bf16* gb[2];
+    const char* ga[2];
+    const char* gb[2];
     int iss_ord = 0, iss_kt = 0, issued = 0;
     auto setup_ptrs = [&](int ord) {
         int m0, n0;
@@ -83,8 +88,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         for (int i = 0; i < 2; ++i) {
             const int rowa = (wave + 8 * i) * 16 + (lane >> 2);
             const int rowb = (wave * 2 + i) * 16 + (lane >> 2);
-            ga[i] = A + (int64_t)min(m0 + rowa, g.M - 1) * g.lda + ((lane & 3) ^ ((4 - ((rowa >> 2) & 3)) & 3)) * 8;
-            gb[i] = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb + ((lane & 3) ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 8;
+            ga[i] = A + (int64_t)min(m0 + rowa, g.M - 1) * g.lda * ES + ((lane & 3) ^ ((4 - ((rowa >> 2) & 3)) & 3)) * 16;
+            gb[i] = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb * ES + ((lane & 3) ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 16;
         }
         // the tile's 256 bias columns ride the same DMA queue (a VGPR load in the epilogue would make hipcc drain it with
         // vmcnt(0)); older than the tile's first operand stage, so the wait that retires that stage retires it too
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     auto issue_one = [&]() {
         if (issued < total) {
             char* st = smem + (issued & 3) * P_STAGE_BYTES;
-            const int k0 = iss_kt * P_BK;
+            const int k0 = iss_kt * 64;                  // bytes
             __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + wave * 1024), 16, 0, 0);
             if (a2) __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave + 8) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + 16384 + (wave * 2) * 1024), 16, 0, 0);
@@ -121,8 +126,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     for (int j = 0; j < 4; ++j) ob[j] = 16384 + p_off(wc * 64 + j * 16 + fr, fg);
 
     // stores one epilogue leaves in flight (known exactly only for a wave whose sub-tile is interior: every store executes)
-    constexpr int ST1 = 2 * NI, ST2 = 4 * NI;
+    constexpr int ST1 = 2 * NI, ST2 = 4 * NI, ST3 = 6 * NI;
     int pend = 0;
+    const bool QE = FP8 && EPI == EPI_GELU && g.q_out != nullptr;      // workgroup-uniform
+    float amax_l = 0.f;
     int cs = 0;                                          // compute step, counted across tiles (ring stage = cs & 3)
     for (int ord = 0; ord < my_tiles; ++ord) {
         f32x4_t acc[NI][4];
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             if (younger >= 2) {
                 if (kt < 3 && pend == ST1) { if (a2) wait_vm<8 + ST1>(); else wait_vm<6 + ST1>(); }
                 else if (kt < 3 && pend == ST2) { if (a2) wait_vm<8 + ST2>(); else wait_vm<6 + ST2>(); }
+                else if (FP8 && kt < 3 && pend == ST3) { if (a2) wait_vm<8 + ST3>(); else wait_vm<6 + ST3>(); }
                 else if (a2) wait_vm<8>();
                 else wait_vm<6>();
             } else if (younger == 1) {
@@ -149,23 +157,66 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done with step cs - 1
             issue_one();                                 // step cs + 3 refills the stage step cs - 1 occupied
             const char* st = smem + (cs & 3) * P_STAGE_BYTES;
-            bf16x8_t fa[NI], fb[4];
+            constexpr int H0 = (NI + 1) / 2;
+            // the second half of the activation fragments is read UNDER the first half's MFMAs
+            if constexpr (!FP8) {
+                bf16x8_t fa[NI], fb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + ob[j]);
+                for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + ob[j]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < H0; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+                for (int i = H0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < H0; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = H0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                i64x2_t fa[NI], fb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *(const i64x2_t*)(st + ob[j]);
+#pragma unroll
+                for (int i = 0; i < H0; ++i) fa[i] = *(const i64x2_t*)(st + oa[i]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = H0; i < NI; ++i) fa[i] = *(const i64x2_t*)(st + oa[i]);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < H0; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][1], fa[i][1], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = H0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][1], fa[i][1], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
 
         // ---- epilogue, straight from the accumulators:  acc[i][j][r] = C[m0 + wr*WM + i*16 + fr][n0 + wc*64 + j*16 + 4*fg + r]
         int m0, n0;
         tile_of(ord, m0, n0);
         const int nw = n0 + wc * 64, mw = m0 + wr * WM;
+        float alpha = g.alpha;
+        if (FP8) alpha *= (g.scale_a ? g.scale_a[0] : 1.0f) * (g.scale_b ? g.scale_b[0] : 1.0f);      // per-tensor dequantisation
+        const float qinv = QE ? 1.0f / g.q_scale[0] : 0.f;
         float b4[4][4];
         if (g.bias) {
             // inline asm: a ds_read hipcc can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0) in front of every read)
@@ -217,17 +268,36 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float t = g.alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
+                        float t = alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
                         pre[h][r] = t;
                         if (EPI == EPI_GELU) t = gelu_fast(t);
                         else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
                         else if (EPI == EPI_ADD_AUX) t += x[h][r];
                         v[h][r] = t;
                     }
-                {
+                if (C) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][0], v[0][1]), pk_bf16(v[1][0], v[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][2], v[0][3]), pk_bf16(v[1][2], v[1][3]), false, false);
                     if (ok) *(uint4*)(C + (int64_t)row * g.ldc + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+                if constexpr (FP8 && EPI == EPI_GELU) {
+                    if (QE) {
+                        // the bf16-rounded activation, re-quantised for the next product: 4 + 4 columns per lane before the swap
+                        unsigned d[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned p0 = pk_bf16(v[h][0], v[h][1]), p1 = pk_bf16(v[h][2], v[h][3]);
+                            const float r0 = bf_lo(p0), r1 = bf_hi(p0), r2 = bf_lo(p1), r3 = bf_hi(p1);
+                            if (row < g.M && nw + (j0 + h) * 16 + 4 * fg < g.N)
+                                amax_l = fmaxf(amax_l, fmaxf(fmaxf(fabsf(r0), fabsf(r1)), fmaxf(fabsf(r2), fabsf(r3))));
+                            unsigned w = 0;
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(r0 * qinv), q_clamp(r1 * qinv), w, false);
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(r2 * qinv), q_clamp(r3 * qinv), w, true);
+                            d[h] = w;
+                        }
+                        const auto t = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+                        if (ok) *(uint2*)((char*)g.q_out + (int64_t)row * g.ldq + col) = make_uint2(t[0], t[1]);
+                    }
                 }
                 if (EPI == EPI_GELU && aux) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
@@ -237,7 +307,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             }
         }
         const bool interior = (mw + WM <= g.M) && (nw + 64 <= g.N);      // wave-uniform: every store above was issued
-        pend = interior ? ((EPI == EPI_GELU && aux) ? ST2 : ST1) : 0;
+        pend = interior ? ST1 * ((C ? 1 : 0) + ((EPI == EPI_GELU && aux) ? 1 : 0) + (QE ? 1 : 0)) : 0;
+    }
+    if constexpr (FP8 && EPI == EPI_GELU) {
+        if (QE) {
+            const float m = wave_max(amax_l);
+            if (lane == 0 && m > __uint_as_float(__hip_atomic_load(g.q_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                atomicMax(g.q_amax, __float_as_uint(m));
+        }
     }
 }
 
@@ -291,6 +368,47 @@ static int p256_mode() {
 extern "C" int mvuld_set_gemm_p256_mode(int mode) {
     MV_CHECK_ARG(mode >= 0 && mode <= 2, "set_gemm_p256_mode: mode must be 0, 1 or 2");
     g_p256_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+template <int EPI, int NI>
+static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t stream) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const int tiles_m = (int)cdiv(g.M, 32 * NI);
+    const int nt = tiles_m * tiles_n;
+    const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+}
+static int p256_pick_ni(int M, int tiles_n, int cus);
+template <int EPI>
+static void p256_launch_fp8(const GemmArgs& g, int tiles_n, hipStream_t stream) {
+    switch (p256_pick_ni(g.M, tiles_n, p256_num_cus())) {
+        case 4: p256_launch_fp8_ni<EPI, 4>(g, tiles_n, stream); break;
+        case 5: p256_launch_fp8_ni<EPI, 5>(g, tiles_n, stream); break;
+        case 6: p256_launch_fp8_ni<EPI, 6>(g, tiles_n, stream); break;
+        case 7: p256_launch_fp8_ni<EPI, 7>(g, tiles_n, stream); break;
+        default: p256_launch_fp8_ni<EPI, 8>(g, tiles_n, stream); break;
+    }
+}
+
+int mvuld_gemm_nt_p256_fp8(const GemmArgs& g, hipStream_t stream) {
+    if (g.batch != 1 || g.splitk != 1 || g.out_mode != OUT_STORE) return -1;
+    if (g.K % 64 != 0 || g.K < 256 || g.N % 8 != 0 || g.ldc % 8 != 0 || (((uintptr_t)g.C) & 15) != 0) return -1;
+    if (g.lda % 16 != 0 || g.ldb % 16 != 0 || ((((uintptr_t)g.A) | ((uintptr_t)g.B)) & 15) != 0) return -1;
+    if (g.aux && (g.ldaux % 8 != 0 || (((uintptr_t)g.aux) & 15) != 0)) return -1;
+    if (g.bias && (((uintptr_t)g.bias) & 15) != 0) return -1;
+    if (g.q_out && (g.epi != EPI_GELU || !g.q_scale || !g.q_amax || g.ldq % 8 != 0 || (((uintptr_t)g.q_out) & 7) != 0)) return -1;
+    if (!g.C && !g.q_out) return -1;
+    const int tiles_n = (int)cdiv(g.N, P_BN);
+    switch (g.epi) {
+        case EPI_NONE: case EPI_BIAS: p256_launch_fp8<EPI_BIAS>(g, tiles_n, stream); break;
+        case EPI_GELU: p256_launch_fp8<EPI_GELU>(g, tiles_n, stream); break;
+        default: return -1;
+    }
     return 0;
 }
 

@@ -143,10 +143,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restric
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const bf16* __restrict__ res, const float* __restrict__ rowscale,
                                                            int rows_per_sample, bf16* __restrict__ y, float* __restrict__ mean,
-                                                           float* __restrict__ rstd, int64_t rows, int C, int G, float eps) {
+                                                           float* __restrict__ rstd, int64_t rows, int C, int G, float eps,
+                                                           uint2* __restrict__ q8, float* __restrict__ qstate) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane & (G - 1), rg = lane / G, rpw = 64 / G;
     const int nch = C >> 3;
+    const float qinv = q8 ? 1.0f / qstate[0] : 0.f;      // e4m3 copy of y for the next fp8 product (scale of the previous step)
+    float amax_l = 0.f;
     float ga[CPL][8], be[CPL][8];
     int chc[CPL];
     bool chok[CPL];
@@ -208,6 +211,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restric
                 o.v[e] = (bf16)t;
             }
             if (rok && chok[i]) *(bf16x8*)(y + r * C + chc[i] * 8) = o;
+            if (q8) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (float)o.v[e];
+                if (rok && chok[i]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax_l = fmaxf(amax_l, fabsf(f[e]));
+                }
+                unsigned lo = 0, hi = 0;
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(f[0] * qinv), q_clamp(f[1] * qinv), lo, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(f[2] * qinv), q_clamp(f[3] * qinv), lo, true);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(f[4] * qinv), q_clamp(f[5] * qinv), hi, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(q_clamp(f[6] * qinv), q_clamp(f[7] * qinv), hi, true);
+                if (rok && chok[i]) q8[(r * C >> 3) + chc[i]] = make_uint2(lo, hi);
+            }
+        }
+    }
+    if (q8) {
+        // one atomic per workgroup, and only when it would raise the maximum (thousands of same-address atomics serialise in L2)
+        __shared__ float wmax[4];
+        const float mw = wave_max(amax_l);
+        if (lane == 0) wmax[w] = mw;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            if (m > __hip_atomic_load(qstate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)(qstate + 1), __float_as_uint(m));
         }
     }
 }
@@ -346,9 +375,9 @@ static inline int ln_group(int C) {          // lanes per row
 }
 
 // y = residual + rowscale[row / rows_per_sample] * (LN(x + pre) * gamma + beta); pre/xsum/residual/rowscale optional
-extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
-                                   const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd,
-                                   int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
+static int layernorm_fwd_impl(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
+                              const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd,
+                              int64_t rows, int C, float eps, int dtype, void* q8, float* qstate, hipStream_t stream) {
     MV_CHECK_ARG(rows > 0 && C > 0 && C <= 64 * LN_MAXPL, "layernorm_fwd: rows=%lld C=%d unsupported (C<=1024)", (long long)rows, C);
     MV_CHECK_ARG(x && y && gamma && beta, "layernorm_fwd: null pointer");
     MV_CHECK_ARG(!rowscale || rows_per_sample > 0, "layernorm_fwd: rows_per_sample");
@@ -358,7 +387,7 @@ extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, c
         const int gridv = (int)min((int64_t)4096, cdiv(rows, (int64_t)4 * rpw));
 #define LN_FWD_VEC(CPL, P, R)                                                                                                          \
     hipLaunchKernelGGL((layernorm_fwd_vec_k<CPL, P, R>), dim3(gridv), dim3(256), 0, stream, (const bf16*)x, (const bf16*)pre, (bf16*)xsum, \
-                       gamma, beta, (const bf16*)residual, rowscale, rows_per_sample, (bf16*)y, mean, rstd, rows, C, G, eps)
+                       gamma, beta, (const bf16*)residual, rowscale, rows_per_sample, (bf16*)y, mean, rstd, rows, C, G, eps, (uint2*)q8, qstate)
         const int sel = (C / 8 <= G ? 0 : 4) | (pre ? 2 : 0) | (residual ? 1 : 0);
         switch (sel) {
             case 0: LN_FWD_VEC(1, false, false); break;
@@ -374,6 +403,7 @@ extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, c
         MV_LAUNCH_CHECK("layernorm_fwd_vec");
         return 0;
     }
+    MV_CHECK_ARG(!q8, "layernorm_fwd_q8: bf16, C %% 8 == 0 and 16-byte aligned tensors only");
     const int grid = (int)min((int64_t)2048, cdiv(rows, 4));
     if (dtype == MVULD_F32)
         hipLaunchKernelGGL(layernorm_fwd_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (const float*)pre, (float*)xsum, gamma, beta,
@@ -383,6 +413,19 @@ extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, c
                            (const bf16*)residual, rowscale, rows_per_sample, (bf16*)y, mean, rstd, rows, C, eps);
     MV_LAUNCH_CHECK("layernorm_fwd");
     return 0;
+}
+
+extern "C" int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
+                                   const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd,
+                                   int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
+    return layernorm_fwd_impl(x, pre, xsum, gamma, beta, residual, rowscale, rows_per_sample, y, mean, rstd, rows, C, eps, dtype, nullptr, nullptr, stream);
+}
+// ... and the e4m3 copy of y for the next fp8 product, under the scale in q_state[0]; max|y| folded into q_state[1]
+extern "C" int mvuld_layernorm_fwd_q8(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, const void* residual,
+                                      const float* rowscale, int rows_per_sample, void* y, float* mean, float* rstd,
+                                      int64_t rows, int C, float eps, void* q_out, float* q_state, hipStream_t stream) {
+    MV_CHECK_ARG(q_out && q_state && (((uintptr_t)q_out) & 7) == 0, "layernorm_fwd_q8: null / misaligned e4m3 output");
+    return layernorm_fwd_impl(x, pre, xsum, gamma, beta, residual, rowscale, rows_per_sample, y, mean, rstd, rows, C, eps, MVULD_BF16, q_out, q_state, stream);
 }
 
 extern "C" int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,

@@ -86,6 +86,9 @@ def build_fused_model(config):
     from mvuld_amd.models.GraphModel import Multi_DefectModel_new_GCN
     from mvuld_amd.models.unixcoder import RobertaConfigLite
     ad = act_dtype_of(config)
+    # FUSED.DTYPE fp8: bf16 activations and backward, the encoders' forward QKV / FFN products on the fp8 matrix cores
+    from mvuld_amd import ops
+    ops.FP8_FWD[0] = str(config.FUSED.DTYPE).lower() in ("fp8", "e4m3")
     if config.FUSED.ENABLE:
         t = config.FUSED.TEXT
         attn_drop = float(t.ATTN_DROPOUT)

@@ -41,6 +41,19 @@ class FusedMVulD(nn.Module):
         return self.swin.no_weight_decay_keywords()
 
     def forward(self, g, images, source_ids, seq_lens=None, node_ids=None, node_lens=None):
+        from .. import ops
+        if not (ops.FP8_FWD[0] and images.is_cuda):
+            return self._forward(g, images, source_ids, seq_lens, node_ids, node_lens)
+        # fp8 forward GEMMs (configs[4]): last pass's amax of every fused quantisation site becomes this pass's scale, once for both
+        # encoders and before their streams fork
+        ops.fp8_roll(images.device)
+        ops.FP8_IN_FUSED[0] = True
+        try:
+            return self._forward(g, images, source_ids, seq_lens, node_ids, node_lens)
+        finally:
+            ops.FP8_IN_FUSED[0] = False
+
+    def _forward(self, g, images, source_ids, seq_lens=None, node_ids=None, node_lens=None):
         """The two encoders are independent until the head: the text encoder runs on a second HIP stream so its kernels fill
         the tails of the image encoder's launches (and vice versa); autograd replays each branch's backward on the stream its
         forward ran on.  The side stream is joined before the head and, in backward, when the text encoder's first op has

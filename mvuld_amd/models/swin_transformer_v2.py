@@ -81,7 +81,14 @@ class _SwinBlockFn(torch.autograd.Function):
         ad = x.dtype
         # qkv bias = (q_bias, 0, v_bias)   (:147-150)
         qb = blk._qkv_bias_buf(x.device)
-        qkv = ops.gemm_nt(x, ops.weight(a.qkv.weight, ad), bias=qb)
+        # BASELINE configs[4]: QKV and the two FFN products on the fp8 matrix cores (stages with C >= 256).  Their activation operands
+        # leave their producers already quantised (ops.Fp8Site: LayerNorm / GELU epilogue, delayed scaling): no quantisation pass.
+        fp8 = ops.FP8_FWD[0] and ad == torch.bfloat16 and C >= 256 and C % 64 == 0
+        need_bwd = getattr(blk, "_need_bwd", True)
+        if fp8:
+            qkv = ops.linear_fwd(x, a.qkv.weight, bias=qb, xq=ops.fp8_take(x))
+        else:
+            qkv = ops.gemm_nt(x, ops.weight(a.qkv.weight, ad), bias=qb)
         T2 = (2 * ws - 1) ** 2
         hidden = torch.empty((T2, 512), dtype=torch.float32, device=x.device)
         table16 = torch.empty((T2, H), dtype=torch.float32, device=x.device)
@@ -92,13 +99,21 @@ class _SwinBlockFn(torch.autograd.Function):
         geom = ops.AttnGeom(0, B, H, C // H, ws * ws, (res // ws) ** 2, res, ws, shift)
         att, lse = ops.attn_fwd(geom, qkv, table16, ls)
         proj = ops.gemm_nt(att, ops.weight(a.proj.weight, ad), bias=a.proj.bias.data)
-        x1, mean1, rstd1, _ = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x,
-                                                rowscale=rowscale, rows_per_sample=L)
-        hpre = torch.empty((x.shape[0], blk.mlp.fc1.weight.shape[0]), dtype=ad, device=x.device)
-        hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre)
-        m = ops.gemm_nt(hact, ops.weight(blk.mlp.fc2.weight, ad), bias=blk.mlp.fc2.bias.data)
-        x2, mean2, rstd2, _ = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1,
-                                                rowscale=rowscale, rows_per_sample=L)
+        x1, mean1, rstd1, _, x1q = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x, rowscale=rowscale,
+                                                     rows_per_sample=L, emit=ops.fp8_site(blk, "x1", x.device) if fp8 else False)
+        # the pre-activation is kept for dGELU only: inference skips that write (and, in fp8, the bf16 copy of the activation too)
+        hpre = torch.empty((x.shape[0], blk.mlp.fc1.weight.shape[0]), dtype=ad, device=x.device) if need_bwd else None
+        if fp8:
+            hact, hq = ops.linear_fwd(x1, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre, xq=x1q,
+                                      emit=ops.fp8_site(blk, "h", x.device), need_out=need_bwd)
+            m = ops.linear_fwd(hact, blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias.data, xq=hq)
+        else:
+            hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre)
+            m = ops.gemm_nt(hact, ops.weight(blk.mlp.fc2.weight, ad), bias=blk.mlp.fc2.bias.data)
+        x2, mean2, rstd2, _, x2q = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1, rowscale=rowscale,
+                                                     rows_per_sample=L,
+                                                     emit=ops.fp8_site(blk, "x2", x.device) if (fp8 and getattr(blk, "_q8_next", False)) else False)
+        ops.fp8_put(x2, x2q)                # the next block's QKV product takes it
         ctx.save_for_backward(x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale)
         ctx.blk, ctx.geom = blk, geom
         return x2
@@ -283,6 +298,7 @@ class SwinTransformerBlock(nn.Module):
 
     def forward(self, x, B, rowscale=None):
         self._batch = B
+        self._need_bwd = torch.is_grad_enabled()
         return _SwinBlockFn.apply(x, self, rowscale)
 
     def flops(self):
@@ -421,8 +437,11 @@ class SwinTransformerV2(nn.Module):
         t = _PatchEmbedFn.apply(x.float(), pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, self.act_dtype)
         scales = self._droppath_scales(B, x.device)
         k = 0
+        if ops.FP8_FWD[0] and not ops.FP8_IN_FUSED[0]:
+            ops.fp8_roll(x.device)
         for layer in self.layers:
-            for blk in layer.blocks:
+            for i, blk in enumerate(layer.blocks):
+                blk._q8_next = i + 1 < len(layer.blocks)
                 rs = scales[k] if (scales is not None and blk.drop_path_rate > 0) else None
                 t = blk(t, B, rs)
                 k += 1

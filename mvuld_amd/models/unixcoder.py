@@ -215,7 +215,13 @@ class _LayerFn(torch.autograd.Function):
         H, nh = cfg.hidden_size, cfg.num_attention_heads
         ad = x.dtype
         sa = layer.attention.self
-        qkv = ops.gemm_nt(x, ops.weight(sa.qkv_weight, ad), bias=sa.qkv_bias.data)
+        # BASELINE configs[4]: QKV and the two FFN products on the fp8 matrix cores; operands quantised by their producers (ops.Fp8Site)
+        fp8 = ops.FP8_FWD[0] and ad == torch.bfloat16 and H >= 256 and H % 64 == 0
+        need_bwd = getattr(layer, "_need_bwd", True)
+        if fp8:
+            qkv = ops.linear_fwd(x, sa.qkv_weight, bias=sa.qkv_bias.data, xq=ops.fp8_take(x))
+        else:
+            qkv = ops.gemm_nt(x, ops.weight(sa.qkv_weight, ad), bias=sa.qkv_bias.data)
         # dropouts of the HF layer (train mode only): attention probabilities inside the fused kernel, hidden states after the
         # attention-output and the FFN-output dense (before their residual LayerNorms); counter-based masks, replayed in backward
         pa = float(cfg.attention_probs_dropout_prob) if layer.training else 0.0
@@ -232,15 +238,22 @@ class _LayerFn(torch.autograd.Function):
         ao = layer.attention.output
         a = ops.gemm_nt(cx, ops.weight(ao.dense.weight, ad), bias=ao.dense.bias.data)
         a = ops.dropout(a, ph, seeds[1])
-        x1, mean1, rstd1, s1 = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps,
-                                                 pre=x, want_sum=True)
+        x1, mean1, rstd1, s1, x1q = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x,
+                                                      want_sum=True, emit=ops.fp8_site(layer, "x1", x.device) if fp8 else False)
         it, ot = layer.intermediate, layer.output
-        ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device)
-        iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
-        o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
+        ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device) if need_bwd else None
+        if fp8:
+            iact, iq = ops.linear_fwd(x1, it.dense.weight, bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre, xq=x1q,
+                                      emit=ops.fp8_site(layer, "h", x.device), need_out=need_bwd)
+            o = ops.linear_fwd(iact, ot.dense.weight, bias=ot.dense.bias.data, xq=iq)
+        else:
+            iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
+            o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
         o = ops.dropout(o, ph, seeds[2])
-        x2, mean2, rstd2, s2 = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps,
-                                                 pre=x1, want_sum=True)
+        x2, mean2, rstd2, s2, x2q = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x1,
+                                                      want_sum=True,
+                                                      emit=ops.fp8_site(layer, "x2", x.device) if (fp8 and getattr(layer, "_q8_next", False)) else False)
+        ops.fp8_put(x2, x2q)                # the next layer's QKV product takes it
         ctx.save_for_backward(x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2)
         ctx.layer, ctx.geom, ctx.hdrop = layer, geom, (ph, seeds[1], seeds[2])
         return x2
@@ -390,8 +403,7 @@ class RobertaModel(nn.Module):
         B, L = source_ids.shape
         x, valid = _EmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, self.embeddings, self.act_dtype)
         x = self._embedding_dropout(x)
-        for layer in self.encoder.layer:
-            x = _LayerFn.apply(x, valid, layer, B, L)
+        x = self._run_layers(x, valid, B, L)
         return x, valid
 
     def _embedding_dropout(self, x):
@@ -423,9 +435,17 @@ class RobertaModel(nn.Module):
         T = packed.total
         x, rowmap = _PackEmbedFn.apply(self.embeddings.word_embeddings.weight, source_ids, packed.cu, T, self.embeddings, self.act_dtype)
         x = self._embedding_dropout(x)
-        for layer in self.encoder.layer:
-            x = _LayerFn.apply(x, packed, layer, B, L)
+        x = self._run_layers(x, packed, B, L)
         return x, packed, rowmap
+
+    def _run_layers(self, x, valid, B, L):
+        if ops.FP8_FWD[0] and not ops.FP8_IN_FUSED[0]:
+            ops.fp8_roll(x.device)
+        n = len(self.encoder.layer)
+        for i, layer in enumerate(self.encoder.layer):
+            layer._need_bwd, layer._q8_next = torch.is_grad_enabled(), i + 1 < n
+            x = _LayerFn.apply(x, valid, layer, B, L)
+        return x
 
     def forward(self, source_ids, attention_mask=None):
         B, L = source_ids.shape

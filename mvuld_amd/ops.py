@@ -165,6 +165,126 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
     return out
 
 
+# --------------------------------------------------------------------------------------------- fp8 forward GEMMs (BASELINE configs[4])
+FP8_IN_FUSED = [False]             # set by the fused model while its forward runs: it rolls the fp8 scales once for both encoders
+FP8_FWD = [False]                    # forward QKV / FFN products of the two encoders on the fp8 matrix cores
+_Q_SCRATCH = {}
+
+
+def fp8_eligible(M, N, K):
+    return K % 64 == 0 and K >= 256 and N % 8 == 0 and M >= 256
+
+
+def quant_fp8(x, out=None, scale=None):
+    """Per-tensor OCP e4m3 quantisation of a contiguous bf16 / fp32 tensor: (q uint8 same shape, scale fp32[1]), x ~= q * scale."""
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    key = (x.device, torch.cuda.current_stream().cuda_stream if x.is_cuda else 0)
+    part = _Q_SCRATCH.get(key)
+    if part is None:
+        part = _Q_SCRATCH[key] = torch.empty(1024, dtype=torch.float32, device=x.device)
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if out is None else out
+    sc = torch.empty(1, dtype=torch.float32, device=x.device) if scale is None else scale
+    call("quant_e4m3", ptr(x), x.numel(), dt(x), ptr(q), ptr(sc), ptr(part))
+    return q, sc
+
+
+def weight_fp8(p):
+    """(e4m3 copy, scale) of a weight [out, in], requantised when the optimizer has stepped (WEIGHT_EPOCH)."""
+    c = getattr(p, "_mv_w8", None)
+    if c is None or p._mv_w8_epoch != WEIGHT_EPOCH[0]:
+        w = p.data if isinstance(p, torch.nn.Parameter) else p
+        q, sc = quant_fp8(w.reshape(w.shape[0], -1), *(c or (None, None)))
+        p._mv_w8 = c = (q, sc)
+        p._mv_w8_epoch = WEIGHT_EPOCH[0]
+    return c
+
+
+class Fp8Site:
+    """One fused quantisation site: a tensor some kernel produces (a LayerNorm output, a GELU activation) and the next fp8 product
+    consumes.  Delayed scaling: the producer writes the e4m3 copy under the scale of the PREVIOUS step while folding max|value| into
+    the site's amax; fp8_roll() turns that into the next step's scale.  `state` = the {scale, amax} pair in device memory.  A site
+    that has never seen data (`cal` False) is calibrated by one dynamic two-pass quantisation, which leaves its scale in the slot."""
+    __slots__ = ("state", "cal")
+
+    def __init__(self, state):
+        self.state, self.cal = state, False
+
+
+_FP8_STATE = {}      # device -> [flat fp32 tensor of {scale, amax} pairs, sites handed out]
+_FP8_MAX_SITES = 4096
+_FP8_SIDE = {}       # data_ptr of a bf16 activation -> (q, scale) emitted beside it for the ONE consumer about to read it
+
+
+def fp8_site(owner, name, device):
+    key = "_mv_q8_" + name
+    st = getattr(owner, key, None)
+    if st is None or st.state.device != device:
+        reg = _FP8_STATE.get(device)
+        if reg is None:
+            reg = _FP8_STATE[device] = [torch.zeros(2 * _FP8_MAX_SITES, dtype=torch.float32, device=device), 0]
+        assert reg[1] < _FP8_MAX_SITES
+        st = Fp8Site(reg[0][2 * reg[1]:2 * reg[1] + 2])
+        reg[1] += 1
+        setattr(owner, key, st)
+    return st
+
+
+def fp8_roll(device):
+    """Start of a forward pass: every site's amax of the last pass becomes its scale (one launch for all sites)."""
+    _FP8_SIDE.clear()
+    reg = _FP8_STATE.get(device)
+    if reg is not None and reg[1] > 0:
+        call("fp8_roll_scales", ptr(reg[0]), reg[1])
+
+
+def fp8_put(x, qpair):
+    if qpair is not None:
+        _FP8_SIDE[x.data_ptr()] = (qpair, x.shape)
+
+
+def fp8_take(x):
+    e = _FP8_SIDE.pop(x.data_ptr(), None)
+    return e[0] if e is not None and e[1] == x.shape else None
+
+
+def gemm_nt_fp8(a8, sa, b8, sb, bias=None, epi=hip.EPI_NONE, aux=None, out=None, emit=None, need_out=True):
+    """out[M,N] (bf16) = epi(sa * sb * a8 . b8^T + bias).  emit = Fp8Site: the GELU epilogue also writes the activation as e4m3 under
+    the site's scale -> returns (out, (q, scale)); need_out False (inference) then skips the bf16 copy (out = None)."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None and (need_out or emit is None):
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    q = torch.empty((M, N), dtype=torch.uint8, device=a8.device) if emit is not None else None
+    if hip.TIMING.enabled:
+        hip.TIMING.annotate("gemm_nt_mfma_fp8", 2.0 * M * N * K)
+    call("gemm_nt_fp8", ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), ptr(out), out.stride(0) if out is not None else N, M, N, K, ptr(bias),
+         epi, ptr(aux), aux.stride(0) if aux is not None else 0, ptr(sa), ptr(sb), ptr(q), N, ptr(emit.state) if emit is not None else None)
+    if emit is not None:
+        return out, (q, emit.state[0:1])
+    return out
+
+
+def linear_fwd(x, w_param, bias=None, epi=hip.EPI_NONE, aux=None, xq=None, emit=None, need_out=True):
+    """Forward product of a Linear layer, x[M,K] . W[N,K]^T (+ bias, GELU): on the fp8 matrix cores when FP8_FWD is on and the shape
+    is eligible, else the bf16 / fp32 GEMM.  Weights are quantised once per optimizer step.  The activation operand comes either
+    pre-quantised from its producer (xq = (q, scale): see Fp8Site) or through the dynamic two-pass quantisation here.
+    emit = Fp8Site of the OUTPUT (GELU products only): returns (out, qpair-or-None) instead of out."""
+    src = xq[0] if xq is not None else x
+    if (FP8_FWD[0] and (xq is not None or (x.dtype == torch.bfloat16 and x.is_contiguous()))
+            and fp8_eligible(src.shape[0], w_param.shape[0], src.shape[1])):
+        q, sc = xq if xq is not None else quant_fp8(x)
+        w8, ws = weight_fp8(w_param)
+        if emit is not None and not emit.cal:
+            # first pass through this site: bf16 out now, and its dynamic quantisation (by the consumer) calibrates the slot
+            out = gemm_nt_fp8(q, sc, w8, ws, bias=bias, epi=epi, aux=aux)
+            qo, _ = quant_fp8(out, scale=emit.state[0:1])
+            emit.cal = True
+            return out, (qo, emit.state[0:1])
+        return gemm_nt_fp8(q, sc, w8, ws, bias=bias, epi=epi, aux=aux, emit=emit, need_out=need_out)
+    out = gemm_nt(x, weight(w_param, x.dtype), bias=bias, epi=epi, aux=aux)
+    return (out, None) if emit is not None else out
+
+
 def transpose(x, R=None, C=None, batch=1, out=None):
     R = x.shape[-2] if R is None else R
     C = x.shape[-1] if C is None else C
@@ -325,14 +445,31 @@ def _workspace(device, nbytes):
     return ws
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_per_sample=1, pre=None, want_sum=False):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_per_sample=1, pre=None, want_sum=False, emit=None):
+    """emit = Fp8Site: also leave y as e4m3 for the next fp8 product -> a fifth result, the (q, scale) pair."""
     rows, C = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     xsum = torch.empty_like(x) if (pre is not None and want_sum) else None
+    if emit is False:                      # caller unpacks five results either way
+        call("layernorm_fwd", ptr(x), ptr(pre), ptr(xsum), ptr(gamma), ptr(beta), ptr(residual), ptr(rowscale), rows_per_sample,
+             ptr(y), ptr(mean), ptr(rstd), rows, C, eps, dt(x))
+        return y, mean, rstd, xsum, None
+    if emit is not None and emit.cal and x.dtype == torch.bfloat16 and C % 8 == 0:
+        q = torch.empty((rows, C), dtype=torch.uint8, device=x.device)
+        call("layernorm_fwd_q8", ptr(x), ptr(pre), ptr(xsum), ptr(gamma), ptr(beta), ptr(residual), ptr(rowscale), rows_per_sample,
+             ptr(y), ptr(mean), ptr(rstd), rows, C, eps, ptr(q), ptr(emit.state))
+        return y, mean, rstd, xsum, (q, emit.state[0:1])
     call("layernorm_fwd", ptr(x), ptr(pre), ptr(xsum), ptr(gamma), ptr(beta), ptr(residual), ptr(rowscale), rows_per_sample,
          ptr(y), ptr(mean), ptr(rstd), rows, C, eps, dt(x))
+    if emit is not None:
+        qpair = None
+        if x.dtype == torch.bfloat16 and C % 8 == 0:            # first pass through this site: dynamic quantisation calibrates it
+            q, _ = quant_fp8(y, scale=emit.state[0:1])
+            emit.cal = True
+            qpair = (q, emit.state[0:1])
+        return y, mean, rstd, xsum, qpair
     return y, mean, rstd, xsum
 
 

@@ -167,6 +167,138 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
 
 
+def _e4m3_deq(q):
+    return q.cpu().view(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quant_e4m3_matches_torch_float8(gpu, dtype):
+    """mvuld_quant_e4m3 (per-tensor scale = max|x| / 448, v_cvt_pk_fp8_f32 round-to-nearest-even) against torch's own
+    float8_e4m3fn conversion of x / scale on the host: the same codes byte for byte, bar products that land within one fp32 ulp of
+    a rounding boundary (x * (1 / scale) on the device vs the host's arithmetic)."""
+    from mvuld_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n, amp in ((8, 3.0), (4096 * 33 + 8, 0.02), (1 << 21, 700.0)):
+        x = (torch.randn((n,), generator=g) * amp).to(dtype)
+        x[n // 2] = 0.0
+        q, sc = ops.quant_fp8(x.to(gpu))
+        scale = float(x.float().abs().max()) / 448.0
+        assert abs(float(sc) - scale) <= 1e-6 * scale
+        want = (x.float() * (1.0 / sc.cpu())).to(torch.float8_e4m3fn)
+        got = q.cpu().view(torch.float8_e4m3fn)
+        diff = got.float() != want.float()
+        assert float(diff.float().mean()) < 1e-4, float(diff.float().mean())
+        assert float((got.float() - want.float()).abs().max()) <= 32.0          # at most one code apart (largest e4m3 spacing)
+        assert float(got.float().abs().max()) == 448.0 and float(got.float()[n // 2]) == 0.0
+    z, sz = ops.quant_fp8(torch.zeros(64, dtype=dtype, device=gpu))          # all-zero tensor: finite scale, zero codes
+    assert float(sz) > 0 and int(z.sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(6401, 2056, 576), (20000, 1288, 256), (769, 520, 1024), (25088, 768, 3072), (256, 8, 256)])
+def test_gemm_nt_fp8_vs_dequantised_product(gpu, M, N, K):
+    """The fp8 (OCP e4m3, v_mfma_f32_16x16x32_fp8_fp8) variant of the persistent 256 x 256 kernel: the product of the DEQUANTISED
+    operands in fp32 is what the kernel must return (fp32 accumulation: only the bf16 rounding of the output separates them), with
+    ragged M / N tails, bias, and the GELU epilogue with its pre-activation side output."""
+    from mvuld_amd import ops, hip
+    g = torch.Generator().manual_seed(13)
+    a = ((torch.rand((M, K), generator=g) - 0.5) * 3).to(torch.bfloat16)
+    b = ((torch.rand((N, K), generator=g) - 0.5) * 0.2).to(torch.bfloat16)
+    bias = torch.rand((N,), generator=g) - 0.5
+    qa, sa = ops.quant_fp8(a.to(gpu))
+    qb, sb = ops.quant_fp8(b.to(gpu))
+    ref = (_e4m3_deq(qa).to(gpu) @ _e4m3_deq(qb).to(gpu).t()).cpu() * float(sa) * float(sb)
+    out = ops.gemm_nt_fp8(qa, sa, qb, sb)
+    assert out.dtype == torch.bfloat16 and rel(out, ref) < 4e-3
+    assert float((out.float().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    Bi = bias.to(gpu)
+    out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi)
+    assert rel(out, ref + bias) < 4e-3
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
+    out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux)
+    assert rel(aux, ref + bias) < 4e-3 and rel(out, F.gelu(ref + bias)) < 1e-2
+    # and the quantised product is a faithful stand-in for the bf16 one (e4m3: 3 mantissa bits, errors average out over K)
+    full = (a.float() @ b.float().t())
+    assert rel(ops.gemm_nt_fp8(qa, sa, qb, sb), full) < 6e-2
+
+
+def _site(gpu, scale):
+    from mvuld_amd import ops
+    st = ops.Fp8Site(torch.tensor([scale, 0.0], dtype=torch.float32, device=gpu))
+    st.cal = True
+    return st
+
+
+@pytest.mark.parametrize("M,N,K", [(6401, 2056, 576), (25088, 3072, 768), (300, 264, 256)])
+def test_gemm_nt_fp8_gelu_epilogue_emits_e4m3(gpu, M, N, K):
+    """Fused quantisation in the fp8 GEMM's GELU epilogue: the e4m3 side output must be exactly the e4m3 conversion of the bf16
+    activation the same launch stores (under the site's scale, saturating), max|activation| must land in the site's amax slot, and
+    the fp8-only form (inference: no bf16 copy) must write the same bytes."""
+    from mvuld_amd import ops, hip
+    g = torch.Generator().manual_seed(17)
+    a = ((torch.rand((M, K), generator=g) - 0.5) * 3).to(torch.bfloat16)
+    b = ((torch.rand((N, K), generator=g) - 0.5) * 0.2).to(torch.bfloat16)
+    bias = (torch.rand((N,), generator=g) - 0.5).to(gpu)
+    qa, sa = ops.quant_fp8(a.to(gpu))
+    qb, sb = ops.quant_fp8(b.to(gpu))
+    plain = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias, epi=hip.EPI_GELU)
+    amax = float(plain.float().abs().max())
+    for scale in (amax / 448.0, amax / 448.0 / 3.0):                     # the second one saturates a good part of the tensor
+        site = _site(gpu, scale)
+        aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
+        out, (q, sc) = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias, epi=hip.EPI_GELU, aux=aux, emit=site)
+        assert torch.equal(out, plain) and sc.data_ptr() == site.state.data_ptr()
+        want = (out.float() * (1.0 / torch.tensor(scale, dtype=torch.float32))).clamp(-448, 448).cpu().to(torch.float8_e4m3fn)
+        got = q.cpu().view(torch.float8_e4m3fn)
+        mism = float((got.float() != want.float()).float().mean())
+        assert mism < 1e-4 and float((got.float() - want.float()).abs().max()) <= 32.0, mism
+        assert float(site.state[1]) == amax and float(site.state[0]) == pytest.approx(scale)
+        site.state[1] = 0.0
+        none, (q2, _) = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias, epi=hip.EPI_GELU, emit=site, need_out=False)
+        assert none is None and torch.equal(q2, q) and float(site.state[1]) == amax
+
+
+@pytest.mark.parametrize("rows,C,pre,res", [(6272, 256, False, True), (1000, 768, True, False), (333, 1024, False, True), (50, 512, False, False)])
+def test_layernorm_fwd_q8_emits_e4m3(gpu, rows, C, pre, res):
+    """LayerNorm with the fused e4m3 side output: y / mean / rstd identical to the plain launch, q = e4m3(y / scale) exactly, amax."""
+    from mvuld_amd import ops
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn((rows, C), generator=g) * 2).to(torch.bfloat16).to(gpu)
+    p = torch.randn((rows, C), generator=g).to(torch.bfloat16).to(gpu) if pre else None
+    r = torch.randn((rows, C), generator=g).to(torch.bfloat16).to(gpu) if res else None
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(gpu), (torch.rand(C, generator=g) - 0.5).to(gpu)
+    y0, m0, r0, s0 = ops.layernorm_fwd(x, gam, bet, 1e-5, residual=r, pre=p, want_sum=pre)
+    amax = float(y0.float().abs().max())
+    site = _site(gpu, amax / 448.0 / 1.5)
+    y, m, rs, s, (q, sc) = ops.layernorm_fwd(x, gam, bet, 1e-5, residual=r, pre=p, want_sum=pre, emit=site)
+    assert torch.equal(y, y0) and torch.equal(m, m0) and torch.equal(rs, r0) and (not pre or torch.equal(s, s0))
+    want = (y.float() * (1.0 / site.state[0:1])).clamp(-448, 448).cpu().to(torch.float8_e4m3fn)
+    got = q.cpu().view(torch.float8_e4m3fn)
+    assert float((got.float() != want.float()).float().mean()) < 1e-4 and float((got.float() - want.float()).abs().max()) <= 32.0
+    assert float(site.state[1]) == amax
+    # an uncalibrated site: plain launch + dynamic quantisation that leaves its scale in the slot
+    fresh = ops.Fp8Site(torch.zeros(2, dtype=torch.float32, device=gpu))
+    y2, _, _, _, (q2, sc2) = ops.layernorm_fwd(x, gam, bet, 1e-5, residual=r, pre=p, want_sum=pre, emit=fresh)
+    assert fresh.cal and torch.equal(y2, y0) and float(fresh.state[0]) == pytest.approx(amax / 448.0, rel=1e-6) and float(fresh.state[1]) == 0.0
+    assert float(q2.cpu().view(torch.float8_e4m3fn).float().abs().max()) == 448.0
+
+
+def test_fp8_roll_scales(gpu):
+    from mvuld_amd.hip import call, ptr
+    st = torch.tensor([1.0, 0.0, 2.0, 896.0, 0.0, 4.48], dtype=torch.float32, device=gpu)
+    call("fp8_roll_scales", ptr(st), 3)
+    assert st.cpu().tolist() == pytest.approx([1.0, 0.0, 2.0, 0.0, 0.01, 0.0])
+
+
+def test_gemm_nt_fp8_rejects_ineligible_shapes(gpu):
+    from mvuld_amd import ops, hip
+    qa = torch.zeros((300, 128), dtype=torch.uint8, device=gpu)
+    qb = torch.zeros((64, 128), dtype=torch.uint8, device=gpu)
+    s = torch.ones(1, device=gpu)
+    with pytest.raises(RuntimeError, match="not eligible"):
+        ops.gemm_nt_fp8(qa, s, qb, s)                      # K = 128 < 256
+    assert not ops.fp8_eligible(300, 64, 128) and ops.fp8_eligible(300, 64, 256)
+
+
 def test_fast_erf_gelu_epilogue_accuracy(gpu):
     """bf16-output GEMM epilogues use a 13-instruction erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7): GELU and dGELU through
     an identity product over a dense sweep of pre-activations must match torch's erf GELU to bf16 rounding."""

@@ -717,6 +717,91 @@ def test_fused_full_size_eval_logits_vs_oracle(gpu, dtype):
     assert err < (1e-3 if dtype == torch.float32 else 1e-2)
 
 
+def test_fused_full_size_fp8_eval_logits_vs_oracle(gpu):
+    """BASELINE configs[4] at the north_star's size: the same model with the encoders' forward QKV / FFN products on the fp8 (e4m3)
+    matrix cores (per-tensor scales, fp32 accumulation) -- eval logits against the fp32 CPU oracle.  Three passes: the first
+    calibrates every fused quantisation site dynamically, the later ones run the delayed-scaling path (LayerNorm / GELU epilogue emit
+    e4m3 under the previous pass's scale); on identical inputs all three must agree closely.  No tolerance is published for fp8; the
+    bound written here is 2e-2 absolute on logits of scale ~0.23 (measured values printed), and the run must actually have gone through
+    the fp8 kernel (call counter)."""
+    from oracle import fused_ref
+    from mvuld_amd import ops, hip
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "fp8"], batch_size=2, local_rank=0))
+    orig = ops.gemm_nt_fp8
+    try:
+        model = build_fused_model(config)
+        assert ops.FP8_FWD[0]
+        sd, _ = load_synth_into(model)
+        model = model.to(gpu).eval()
+        f = config.FUSED
+        g, images, ids, labels = synthetic.make_batch([31, 32], config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+        scfg, rcfg = _oracle_cfgs(config)
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        calls = []
+        ops.gemm_nt_fp8 = lambda *a, **k: (calls.append((a[0].shape, k.get("emit") is not None, k.get("need_out", True))), orig(*a, **k))[1]
+        errs = []
+        with torch.no_grad():
+            ref, _, _ = fused_ref.fused_forward(sd, images, ids, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"],
+                                                g.ndata["pos_emb"], scfg, rcfg, training=False)
+            for it in range(3):
+                del calls[:]
+                logits = model(g.to(gpu), images.to(gpu), ids.to(gpu)).float().cpu()
+                errs.append(float((logits - ref).abs().max()))
+                # QKV + the two FFN products: 12 text layers x 3, Swin stages 1-3 (22 blocks) x 3 (stage 0, C = 128, stays bf16)
+                assert len(calls) == 12 * 3 + 22 * 3
+                if it > 0:       # delayed-scaling passes: every FFN-in product emits e4m3 only (inference: no bf16 activation)
+                    assert sum(1 for c in calls if c[1]) == 12 + 22 and all(not c[2] for c in calls if c[1])
+            ops.gemm_nt_fp8 = orig
+            ops.FP8_FWD[0] = False
+            logits16 = model(g.to(gpu), images.to(gpu), ids.to(gpu)).float().cpu()
+        err16 = float((logits16 - ref).abs().max())
+        print(f"[fused full size, fp8 eval] logits abs err per pass {[round(e, 5) for e in errs]} (bf16 {err16:.3e}; "
+              f"logit scale {float(ref.abs().max()):.3f})")
+        assert max(errs) < 2e-2 and bool(torch.isfinite(logits).all())
+    finally:
+        ops.gemm_nt_fp8 = orig
+        ops.FP8_FWD[0] = False
+
+
+def test_fused_full_size_fp8_train_steps_reduce_loss(gpu):
+    """configs[4] in training: fp8 forward products (delayed scaling from the second step on, weights requantised after every
+    optimizer step), bf16 backward -- six steps on one fixed batch must drive the loss down like the bf16 step does."""
+    from mvuld_amd import ops
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "fp8", "TRAIN.BASE_LR", "1e-4"], batch_size=8, local_rank=0))
+    torch.manual_seed(3)
+    try:
+        model = build_fused_model(config).to(gpu).train()
+        opt = build_optimizer(config, model)
+        f = config.FUSED
+        g, images, ids, labels = synthetic.make_batch(list(range(60, 68)), config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+        g, images, ids, labels = g.to(gpu), images.to(gpu), ids.to(gpu), labels.to(gpu)
+        losses = []
+        for _ in range(6):
+            loss, _ = cross_entropy(model(g, images, ids), labels)
+            loss.backward()
+            norm = opt.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+            assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
+        print("[full-size fp8 train] losses", [round(x, 4) for x in losses])
+        assert losses[-1] < losses[0] - 0.03
+    finally:
+        ops.FP8_FWD[0] = False
+
+
 def test_fused_full_size_batch_permutation_property(gpu):
     """Size-independent property at the full model size: every function's logits depend only on that function (eval mode: running
     BatchNorm statistics, no dropout), so reversing the order of a batch of 8 -- different image rows, token rows, graph node ranges,
