@@ -42,6 +42,23 @@ __device__ __forceinline__ bool am_keep(unsigned elem, unsigned seed, unsigned t
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
 typedef float __attribute__((ext_vector_type(4))) f32x4_t;
+// Explicit two-wide fp32 math for the softmax fix-ups: left to itself the SLP vectoriser pairs elements (1,2),(3,4).. of an
+// accumulator quad, and every v_pk_mul_f32 then costs two v_mov to build its operand pair plus v_alignbit / v_perm to re-pack the
+// bf16 fragment (28 of the 98 VALU instructions of a 64-key dQ block).  Register pairs (0,1),(2,3) of an MFMA result are aligned.
+typedef float __attribute__((ext_vector_type(2))) f32x2_t;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
+typedef bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+__device__ __forceinline__ unsigned am_pk(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+#ifndef AM_X
+#define AM_X 0      // timing experiments (tools/attn_variants.sh): 1 = no exp, 2 = no bias reads, 3 = no transposed reads
+#endif
+__device__ __forceinline__ f32x2_t am_exp2(f32x2_t v) {
+#if AM_X == 1
+    return v * 0.001f;
+#else
+    return (f32x2_t){__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+#endif
+}
 
 #define LN100 4.605170185988092f
 #define NEG_BIG -1.0e30f
@@ -107,7 +124,21 @@ __device__ __forceinline__ int am_xcd_order(int bid, int total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int HD>
+// LDS image of a [rows][HD] bf16 operand tile, read two ways: 16-byte fragments of 16 consecutive rows (ds_read_b128) and transposed
+// 8-byte pieces of 4 x 4 consecutive rows (ds_read_b64_tr_b16: 16 lanes = 4 rows x 32 bytes).
+//   PAD (HD = 64, and the bias-gradient pass): rows padded to HD + 8 elements.  At HD = 64 (144 B = 36 banks) both patterns are
+//        conflict free; at HD = 32 (80 B = 20 banks) four consecutive rows of a transposed read span 68 banks: 2-way conflict.
+//   SWZ (HD = 32): 64-byte rows, the four 16-byte chunks of a row XOR-ed with ((row >> 1 & 1) << 1 | (row >> 2 & 1)): eight
+//        consecutive rows put one chunk in eight different bank groups, four consecutive rows put a chunk PAIR in four different
+//        ones; a row and row + 16 share the swizzle, so the "+ 16 rows" immediate offsets survive.  20 % less LDS, too.
+template <int HD, bool SWZ> struct AmTile { static constexpr int LD = SWZ ? HD : HD + 8; };
+template <int HD, bool SWZ>
+__device__ __forceinline__ int am_off(int row, int chunk) {
+    if (SWZ) return row * HD + ((chunk ^ ((((row >> 1) & 1) << 1) | ((row >> 2) & 1))) << 3);
+    return row * (HD + 8) + (chunk << 3);
+}
+
+template <int HD, bool SWZ = (HD == 32)>
 __device__ __forceinline__ void stage_tile(const AttnGeom& g, const bf16* __restrict__ base, int64_t rowstride, int coloff, int b,
                                            int w, int n0, int rows, bf16* rm, bool normalize, float mul) {
     constexpr int CPR = HD / 8;
@@ -138,7 +169,7 @@ __device__ __forceinline__ void stage_tile(const AttnGeom& g, const bf16* __rest
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[u].e[e] = (bf16)(f[e] * sc);
             }
-            if (c < total) *(uint4*)(rm + (c / CPR) * (HD + 8) + (c % CPR) * 8) = x[u].u;
+            if (c < total) *(uint4*)(rm + am_off<HD, SWZ>(c / CPR, c % CPR)) = x[u].u;
         }
     }
 }
@@ -146,12 +177,16 @@ __device__ __forceinline__ void stage_tile(const AttnGeom& g, const bf16* __rest
 // A operand = transposed 16(dims d0..d0+15) x 32(row slots) fragment of a row-major image rm[rows][ld]:
 // k-slot (g, j<4) <-> row r0+4g+j, (g, j>=4) <-> row r0+16+4g+j-4.  ds_read_b64_tr_b16: within each group of 16 lanes,
 // lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
-__device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int ld, int d0, int r0, int lane) {
+template <int HD, bool SWZ = (HD == 32)>
+__device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int d0, int r0, int lane) {
     typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
     const int fg = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const bf16* a0 = rm + (r0 + 4 * fg + q) * ld + d0 + 4 * pp;
+#if AM_X == 3
+    return *(const bf16x8_t*)(rm + am_off<HD, SWZ>(r0 + (lane & 15), (d0 >> 3) + (fg & 1)));
+#endif
+    const bf16* a0 = rm + am_off<HD, SWZ>(r0 + 4 * fg + q, (d0 >> 3) + (pp >> 1)) + 4 * (pp & 1);
     const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)a0);
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 16 * ld));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 16 * AmTile<HD, SWZ>::LD));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -169,6 +204,9 @@ __device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int ld, int d0, int 
 template <int MODE, bool MASK, bool TAIL, bool G4>
 __device__ __forceinline__ f32x4_t am_bias4(const int (&ki)[4], const char* tabx) {
     f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+#if AM_X == 2
+    return b;
+#endif
     if (MODE == 0) {
         if (G4) {
             const float* a = (const float*)(tabx + ((MASK || TAIL) ? (ki[0] & 0xffff) : ki[0]));
@@ -201,7 +239,6 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
                                              const bf16x8_t (&qf)[HD / 32], const char* tabq, int regq, int vq, int lane, float& m,
                                              f32x4_t& lacc, f32x4_t (&oacc)[HD / 16], const bf16x8_t& ones, unsigned ebase = 0,
                                              unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
-    constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT];
     int ki[NT][4];
@@ -212,7 +249,7 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
         s[t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq);
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks)
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8), qf[ks], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + am_off<HD, HD == 32>(kb + 16 * t + fc, ks * 4 + fg)), qf[ks], s[t], 0, 0, 0);
     }
     float bm = NEG_BIG;
 #pragma unroll
@@ -225,19 +262,29 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
     bm = max4g(bm);
     const float mn = fmaxf(m, bm);
     const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    bf16x8_t pb[NT / 2], pu[DROP ? NT / 2 : 1];      // pb multiplies V (dropped-out when DROP); the denominator sums the undropped pu
+    u32x4_t pw[NT / 2], puw[DROP ? NT / 2 : 1];      // pw multiplies V (dropped-out when DROP); the denominator sums the undropped puw
+    const f32x2_t mn2 = {mn, mn};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[t][r] - mn);
+        for (int hp = 0; hp < 2; ++hp) {
+            const f32x2_t p = am_exp2((f32x2_t){s[t][2 * hp], s[t][2 * hp + 1]} - mn2);
             if (DROP) {
-                pu[t >> 1][(t & 1) * 4 + r] = (bf16)p;
-                pb[t >> 1][(t & 1) * 4 + r] = (bf16)(am_keep(ebase + kb + 16 * t + 4 * fg + r, dseed, dthr) ? p * dinv : 0.f);
+                f32x2_t pd;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) pd[e] = am_keep(ebase + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? p[e] * dinv : 0.f;
+                puw[t >> 1][(t & 1) * 2 + hp] = am_pk(p);
+                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(pd);
             } else {
-                pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(p);
             }
         }
+    bf16x8_t pb[NT / 2], pu[DROP ? NT / 2 : 1];
+#pragma unroll
+    for (int pr = 0; pr < NT / 2; ++pr) {
+        pb[pr] = __builtin_bit_cast(bf16x8_t, pw[pr]);
+        if (DROP) pu[pr] = __builtin_bit_cast(bf16x8_t, puw[pr]);
+    }
     m = mn;
     lacc *= alpha;
 #pragma unroll
@@ -247,7 +294,7 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
         oacc[d] *= alpha;
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr)
-            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Vs, KLD, d * 16, kb + 32 * pr, lane), pb[pr], oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr<HD>(Vs, d * 16, kb + 32 * pr, lane), pb[pr], oacc[d], 0, 0, 0);
     }
 }
 
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
                                                        const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                        bf16* __restrict__ out, float* __restrict__ lse, int Npad, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KLD = HD + 8;
+    constexpr int KLD = AmTile<HD, HD == 32>::LD;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]  (normalised for MODE 0)
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
@@ -283,8 +330,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     }
     int C0 = 0;
     float tau = 1.f;
+    const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
     if (MODE == 0) {
-        const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
         // stored REVERSED: entry (bq - ok) of the table sits at word T2-1-bq + ok, so the entries of consecutive keys ascend
         for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)(T2 - 1 - i) * g.H + h] * LOG2E;
         C0 = T2 - 1 - ((g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1));
@@ -383,7 +430,6 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
                                             const bf16x8_t (&qf)[HD / 32], const bf16x8_t (&dof)[HD / 32], const char* tabq, int regq, int vq,
                                             float L2q, const f32x4_t& negD, int lane, f32x4_t (&dq)[HD / 16], unsigned ebase = 0,
                                             unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
-    constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
     int ki[NT][4];
@@ -395,27 +441,35 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
         dp[t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : negD;         // with dropout the mask sits between dO.V^T and -delta
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
-            const int o = (kb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
+            const int o = am_off<HD, HD == 32>(kb + 16 * t + fc, ks * 4 + fg);
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o), qf[ks], s[t], 0, 0, 0);
             dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o), dof[ks], dp[t], 0, 0, 0);
         }
     }
-    bf16x8_t dsb[NT / 2];
+    u32x4_t dsw[NT / 2];
+    const f32x2_t L2 = {L2q, L2q};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sv = s[t][r];
-            if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, ki[t][r], regq, vq);      // padding keys -> NEG_BIG -> p = 0
-            float dpv = dp[t][r];
-            if (DROP) dpv = (am_keep(ebase + kb + 16 * t + 4 * fg + r, dseed, dthr) ? dpv * dinv : 0.f) + negD[0];
-            dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(__builtin_amdgcn_exp2f(sv - L2q) * dpv);
+        for (int hp = 0; hp < 2; ++hp) {
+            f32x2_t sv = {s[t][2 * hp], s[t][2 * hp + 1]}, dpv = {dp[t][2 * hp], dp[t][2 * hp + 1]};
+            if (MODE != 0 || MASK || TAIL) {                      // padding keys -> NEG_BIG -> p = 0
+                sv[0] = am_mask<MODE, MASK, TAIL>(sv[0], ki[t][2 * hp], regq, vq);
+                sv[1] = am_mask<MODE, MASK, TAIL>(sv[1], ki[t][2 * hp + 1], regq, vq);
+            }
+            if (DROP) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    dpv[e] = (am_keep(ebase + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? dpv[e] * dinv : 0.f) + negD[0];
+            }
+            dsw[t >> 1][(t & 1) * 2 + hp] = am_pk(am_exp2(sv - L2) * dpv);
         }
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d)
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr)
-            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ks, KLD, d * 16, kb + 32 * pr, lane), dsb[pr], dq[d], 0, 0, 0);
+            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr<HD>(Ks, d * 16, kb + 32 * pr, lane), __builtin_bit_cast(bf16x8_t, dsw[pr]),
+                                                            dq[d], 0, 0, 0);
 }
 
 template <int HD, int MODE, bool MASK>
@@ -425,7 +479,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                           float* __restrict__ dlogit_scale, bf16* __restrict__ qt_out, int Npad, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KLD = HD + 8;
+    constexpr int KLD = AmTile<HD, HD == 32>::LD;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]
     bf16* Vs = Ks + (size_t)Npad * KLD;           // [Npad][KLD]
     int* Kinfo = (int*)(Vs + (size_t)Npad * KLD); // [Npad]
@@ -605,8 +659,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // item / dy / key-row arithmetic stays scalar
     const int ws = g.ws;
 
-    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);
-    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
+    stage_tile<HD, false>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);          // padded rows: b128 reads only here
+    stage_tile<HD, false>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) Ktok[i] = (int)am_token(g, b, w, min(i, g.N - 1));
     for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = table16[(int64_t)i * g.H + h] * LOG2E; dtab[i] = 0.f; }
     __syncthreads();
@@ -779,7 +833,6 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
                                              const bf16x8_t (&vf)[HD / 32], const char* tabk, int regk, int vk, int lane,
                                              f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16], unsigned ebase = 0, unsigned NL = 0,
                                              unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
-    constexpr int KLD = HD + 8;
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
     int qi[NT][4];
@@ -792,30 +845,40 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
         dp[t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : nD;
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
-            const int o = (qb + 16 * t + fc) * KLD + ks * 32 + fg * 8;
+            const int o = am_off<HD, HD == 32>(qb + 16 * t + fc, ks * 4 + fg);
             s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Qs + o), kf[ks], s[t], 0, 0, 0);
             dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ds + o), vf[ks], dp[t], 0, 0, 0);
         }
     }
-    bf16x8_t pb[NT / 2], dsb[NT / 2];
+    u32x4_t pw[NT / 2], dsw[NT / 2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float4 l4 = *(const float4*)(Ql + qb + 16 * t + 4 * fg);
-        const float L[4] = {l4.x, l4.y, l4.z, l4.w};
+        const f32x4_t l4 = *(const f32x4_t*)(Ql + qb + 16 * t + 4 * fg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sv = s[t][r];
-            if (MODE != 0 || MASK || TAIL) sv = am_mask<MODE, MASK, TAIL>(sv, qi[t][r], regk, vk);
-            const float p = __builtin_amdgcn_exp2f(sv - L[r]);                 // padding queries -> NEG_BIG -> 0
+        for (int hp = 0; hp < 2; ++hp) {
+            f32x2_t sv = {s[t][2 * hp], s[t][2 * hp + 1]};
+            const f32x2_t L = {l4[2 * hp], l4[2 * hp + 1]}, dpv = {dp[t][2 * hp], dp[t][2 * hp + 1]};
+            if (MODE != 0 || MASK || TAIL) {
+                sv[0] = am_mask<MODE, MASK, TAIL>(sv[0], qi[t][2 * hp], regk, vk);
+                sv[1] = am_mask<MODE, MASK, TAIL>(sv[1], qi[t][2 * hp + 1], regk, vk);
+            }
+            const f32x2_t p = am_exp2(sv + L);                                  // L = -lse; padding queries -> NEG_BIG -> 0
             if (DROP) {
                 // element (query qb+16t+4fg+r, this lane's key): ebase already holds (b, h) and the key
-                const bool keep = am_keep(ebase + (unsigned)(qb + 16 * t + 4 * fg + r) * NL, dseed, dthr);
-                const float nd = Qd[qb + 16 * t + 4 * fg + r];
-                pb[t >> 1][(t & 1) * 4 + r] = (bf16)(keep ? p * dinv : 0.f);
-                dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * ((keep ? dp[t][r] * dinv : 0.f) + nd));
+                f32x2_t pd, ds;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * hp + e;
+                    const bool keep = am_keep(ebase + (unsigned)(qb + 16 * t + 4 * fg + r) * NL, dseed, dthr);
+                    const float nd = Qd[qb + 16 * t + 4 * fg + r];
+                    pd[e] = keep ? p[e] * dinv : 0.f;
+                    ds[e] = p[e] * ((keep ? dpv[e] * dinv : 0.f) + nd);
+                }
+                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(pd);
+                dsw[t >> 1][(t & 1) * 2 + hp] = am_pk(ds);
             } else {
-                pb[t >> 1][(t & 1) * 4 + r] = (bf16)p;
-                dsb[t >> 1][(t & 1) * 4 + r] = (bf16)(p * dp[t][r]);
+                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(p);
+                dsw[t >> 1][(t & 1) * 2 + hp] = am_pk(p * dpv);
             }
         }
     }
@@ -823,8 +886,8 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
     for (int d = 0; d < HD / 16; ++d)
 #pragma unroll
         for (int pr = 0; pr < NT / 2; ++pr) {
-            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Ds, KLD, d * 16, qb + 32 * pr, lane), pb[pr], dv[d], 0, 0, 0);
-            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr(Qs, KLD, d * 16, qb + 32 * pr, lane), dsb[pr], dk[d], 0, 0, 0);
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr<HD>(Ds, d * 16, qb + 32 * pr, lane), __builtin_bit_cast(bf16x8_t, pw[pr]), dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr<HD>(Qs, d * 16, qb + 32 * pr, lane), __builtin_bit_cast(bf16x8_t, dsw[pr]), dk[d], 0, 0, 0);
         }
 }
 
@@ -834,7 +897,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv, int Npad, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KLD = HD + 8;
+    constexpr int KLD = AmTile<HD, HD == 32>::LD;
     bf16* Qs = (bf16*)smem;                       // [Npad][KLD]   q~ * log2(e)
     bf16* Ds = Qs + (size_t)Npad * KLD;           // [Npad][KLD]   dO
     float* Ql = (float*)(Ds + (size_t)Npad * KLD);// [Npad] lse * log2(e)
@@ -855,8 +918,8 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const unsigned dseed = drop ? am_seed(g) : 0u;
     int C0 = 0;
     float qmul = g.scale;
+    const int T2 = MODE == 0 ? (2 * g.ws - 1) * (2 * g.ws - 1) : 0;
     if (MODE == 0) {
-        const int T2 = (2 * g.ws - 1) * (2 * g.ws - 1);
         for (int i = threadIdx.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;
         C0 = (g.ws - 1) * (2 * g.ws - 1) + (g.ws - 1);
         qmul = __expf(fminf(logit_scale[h], LN100));
@@ -871,7 +934,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
             L = lse[lse0 + i] * LOG2E;
             D = delta[am_token(g, b, w, i) * g.H + h];
         }
-        Ql[i] = L;
+        Ql[i] = -L;                // negated, like delta: the block adds it (v_pk_add_f32)
         Qd[i] = -D;
     }
     __syncthreads();
@@ -1044,7 +1107,8 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
-    const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)T2 * 4;
+    const int ld = hd == 32 ? 32 : hd + 8;          // AmTile: swizzled 64-byte rows at hd = 32, padded rows at 64
+    const size_t bytes = (size_t)2 * Npad * ld * 2 + (size_t)Npad * 4 + (size_t)T2 * 4;
     const int qsplit = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * qsplit);
     // 16 waves (4 per SIMD) hide the LDS / MFMA latencies of the score loop twice as well as 8; MVULD_ATTN_FWD_THREADS overrides
@@ -1094,8 +1158,9 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                            ws_delta, ntok, H, hd);
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);
-    const size_t bytes_q = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
-    const size_t bytes_k = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 12 + (size_t)T2 * 4;
+    const int ld = hd == 32 ? 32 : hd + 8;
+    const size_t bytes_q = (size_t)2 * Npad * ld * 2 + (size_t)Npad * 4 + 64 + (size_t)T2 * 4;
+    const size_t bytes_k = (size_t)2 * Npad * ld * 2 + (size_t)Npad * 12 + (size_t)T2 * 4;
 #define AM_BWD(HDV, MODEV, MASKV)                                                                                       \
     do {                                                                                                                 \
         if (am_set_lds(attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>, bytes_q, "attn_bwd_dq_mfma_k")) return 1;                  \

@@ -11,7 +11,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvuld_hip.so")
+LIB_PATH = os.environ.get("MVULD_HIP_LIB") or os.path.join(_HERE, "libmvuld_hip.so")     # override: A/B runs of a variant build
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mvuld_hip.h")
 
 F32, BF16 = 0, 1

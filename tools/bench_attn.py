@@ -9,7 +9,10 @@ B = int(os.environ.get("B", 32))
 cases = [("swin s0", 0, 4, 32, 112, 28, 14), ("swin s0 noshift", 0, 4, 32, 112, 28, 0), ("swin s1", 0, 8, 32, 56, 28, 14),
          ("swin s2", 0, 16, 32, 28, 28, 0), ("swin s3", 0, 32, 32, 14, 14, 0), ("roberta", 1, 12, 64, 0, 0, 0)]
 which = sys.argv[1:] or ["auto"]
+only = os.environ.get("CASES")
 for name, mode, H, hd, res, ws, shift in cases:
+    if only and only not in name:
+        continue
     C = H * hd
     if mode == 0:
         N, nW = ws * ws, (res // ws) ** 2
