@@ -23,7 +23,7 @@ def load_pmc(d):
     for f in files:
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            if "gemm_" not in n:
+            if "gemm_" not in n or "reduce" in n:          # the slab reduction follows its tn256 launch: not a GEMM dispatch
                 continue
             k = int(r["Dispatch_Id"])
             e = per.setdefault(k, {"name": n.split("(")[0][:48], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),

@@ -15,6 +15,12 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(n):
     n = n.split("(")[0]
+    # the NT GEMM family bench.py's roofline names "gemm_nt_mfma_bf16": every bf16-storage matrix-core NT kernel (persistent 256x256,
+    # LDS-DMA rings, the generic tile kernel); "<float" = fp32 output = the head's 3-term-split products, kept apart
+    if "gemm_nt" in n and "simple" not in n:
+        return "gemm_nt_mfma_bf16(split3 fp32)" if "<float" in n else "gemm_nt_mfma_bf16"
+    if "gemm_tn256_k" in n or "gemm_tn_mfma" in n:
+        return "gemm_tn_wgrad"
     for k in ("gemm_nt_mfma_bf16", "gemm_tn_mfma_bf16", "gemm_nt_simple", "attn_fwd_mfma_k", "attn_bwd_dq_mfma_k", "attn_bwd_dkv_mfma_k",
               "attn_bwd_dbias_mfma_k", "attn_delta_k", "layernorm_fwd_k", "layernorm_bwd_k", "batchnorm_fwd_k", "batchnorm_bwd_k",
               "transpose_k", "colsum_k", "adamw_k", "cpb_bwd_k", "cpb_fwd_k", "gat_", "embed_", "cast_k", "sumsq_k"):
@@ -24,7 +30,8 @@ def short(n):
 
 
 def kernel_stats(sub, out):
-    rows = list(csv.DictReader(open(f"{src}/{sub}/r01_kernel_stats.csv")))
+    import glob
+    rows = list(csv.DictReader(open(glob.glob(f"{src}/{sub}/*kernel_stats.csv")[0])))
     with open(out, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
@@ -35,14 +42,16 @@ def kernel_stats(sub, out):
 # kt: MVULD_CONCURRENT=0 (one stream: per-kernel durations comparable with bench.py's live HIP-event timing)
 # kt2: default two-stream run (durations of overlapping kernels stretch; the wall clock is what bench.py reports)
 kernel_stats("kt", f"profiles/{tag}_kernel_stats.csv")
-if os.path.exists(f"{src}/kt2/r01_kernel_stats.csv"):
+if os.path.isdir(f"{src}/kt2"):
     kernel_stats("kt2", f"profiles/{tag}_kernel_stats_two_streams.csv")
 
 agg = collections.defaultdict(lambda: {"n": 0, "fetch": 0.0, "write": 0.0, "ns": 0})
 for kind in ("fetch", "write"):
-    p = f"{src}/{kind}/r01_counter_collection.csv"
-    if not os.path.exists(p):
+    import glob
+    ps = glob.glob(f"{src}/{kind}/*counter_collection.csv")
+    if not ps:
         continue
+    p = ps[0]
     for r in csv.DictReader(open(p)):
         k = short(r["Kernel_Name"])
         a = agg[k]
