@@ -605,11 +605,11 @@ def test_cross_entropy_adamw_sumsq(gpu):
     call("clip_coef", ptr(ss), float(g0.norm() * 0.5), 1.0, ptr(no))
     for step in (1, 2, 3):
         opt.step()
-        call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, step, ptr(no), 0)
+        call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, step, ptr(no), 0, None)
     assert rel(no[0], g0.norm()) < 1e-5 and abs(float(no[1]) - 0.5) < 1e-4
     assert rel(P, p.data) < 1e-5 and rel(P16, p.data) < 1e-2
     assert float(G.abs().max()) > 0                     # zero_grad = 0 leaves the gradient alone ...
-    call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, 4, ptr(no), 1)
+    call("adamw", ptr(P), ptr(G), ptr(M_), ptr(V_), ptr(P16), n, 1e-2, 0.9, 0.999, 1e-8, 0.005, 4, ptr(no), 1, None)
     assert float(G.abs().max()) == 0.0                  # ... zero_grad = 1 clears it in the same pass
 
 
