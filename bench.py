@@ -43,8 +43,12 @@ def parse():
     ap.add_argument("--opts", nargs="+", default=None)
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train: BASELINE configs[1]/[2] (the headline); infer: configs[3], hipGraph-captured eval forward (use --batch 256)")
+    ap.add_argument("--text-min-tokens", type=int, default=0,
+                    help="non-pad tokens per synthetic function ~ U[this, SEQ_LEN]; 0 (default) = SEQ_LEN: BASELINE's 512-token functions, "
+                         "every row full, so the pad-free text encoder skips nothing.  The U[128, 512] case is reported beside it (varlen_text)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the extra U[128, 512]-token leg (varlen_text)")
     ap.add_argument("--no-infer", action="store_true", help="train mode: skip the extra batch-256 hipGraph inference leg")
     ap.add_argument("--graph", action="store_true", help="train mode, N=1: replay the step as ONE captured hipGraph (mvuld_amd/graph_step.py) "
                     "instead of enqueueing it from Python; off by default: on ROCm 7.2 a replay of the ~1900-node, 3-stream graph costs "
@@ -70,7 +74,8 @@ def build(args, device, rank):
     sched = build_scheduler(config, opt, 1000)
     f = config.FUSED
     idx = [rank * args.batch + i for i in range(args.batch)]
-    g, images, ids, labels = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g, images, ids, labels = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI,
+                                                  tok_lo=args.text_min_tokens or f.SEQ_LEN)
     g.index()                                    # CSR index on the host, as the data loader's collate does
     lens = (ids != 1).sum(1).to(torch.int32)     # non-pad tokens per function, counted on the host (main_bigvul.model_step_inputs)
     g = g.to(device)
@@ -195,6 +200,29 @@ def main():
     model.max_steps_in_flight = 2
     fence()
 
+    # The same step on functions of U[128, 512] tokens (what the reference's padded [B, 512] rows really hold): the text encoder runs
+    # pad-free on the packed tokens, so it does proportionally less work.  Reported beside the headline, never as the headline.
+    varlen = None
+    if world_size() == 1 and not args.text_min_tokens and not args.no_varlen:
+        from mvuld_amd.data import synthetic as _syn
+        f_ = config.FUSED
+        ids_v = _syn.make_batch(list(range(args.batch)), 8, f_.SEQ_LEN, f_.TEXT.VOCAB, 2, 3, tok_lo=128)[2]
+        lens_v = (ids_v != 1).sum(1).to(torch.int32)
+        ids_v = ids_v.to(device)
+        main_ids, main_lens = ids, lens
+        ids, lens = ids_v, lens_v
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dtv = time.perf_counter() - t0
+        varlen = {"text_tokens_nonpad_frac": round(float(lens_v.sum()) / ids_v.numel(), 4), "value": round(args.batch * args.steps / dtv, 3),
+                  "unit": "functions/s", "ms_per_step": round(dtv / args.steps * 1e3, 3)}
+        ids, lens = main_ids, main_lens
+
     roofline = None
     if not args.no_kernel_timing:
         hip.TIMING.enable()
@@ -234,7 +262,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_ms if graphed is not None else host_unthrottled_ms, 3),
                        "host_enqueue_eager_ms_per_step": round(host_unthrottled_ms, 2),
                        "text_tokens_nonpad_frac": round(float(lens.sum()) / ids.numel(), 4), "final_loss": round(loss_val, 5)},
-            "roofline": roofline, "cpu_baseline": cpu, "inference": inference,
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "varlen_text": varlen,
         }
         print(json.dumps(out))
     if world_size() > 1:
@@ -253,7 +281,8 @@ def infer_leg(args, config, model, device, world, steps=5, warmup=2):
     f = config.FUSED
     rank = int(os.environ.get("RANK", 0))
     idx = [10_000 + rank * B + i for i in range(B)]
-    g, images, ids, _ = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g, images, ids, _ = synthetic.make_batch(idx, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI,
+                                             tok_lo=args.text_min_tokens or f.SEQ_LEN)      # full 512-token rows, as the headline
     g.index()
     plan = RobertaModel.pack_plan((ids != 1).sum(1), device, ids.shape[1])      # device-resident cu_seqlens: no host work inside the graph
     g, images, ids = g.to(device), images.to(device), ids.to(device)

@@ -84,11 +84,12 @@ def make_label(index: int, salt=0) -> int:
     return int(synth.unit(f"label/{index}", 1, salt)[0] > 0)
 
 
-def make_batch(indices, img_size=448, seq_len=512, vocab=51416, n_lo=150, n_hi=250, salt=0):
-    """(graph, images [B,3,S,S], ids [B,L], labels [B]) for the fused model."""
+def make_batch(indices, img_size=448, seq_len=512, vocab=51416, n_lo=150, n_hi=250, salt=0, tok_lo=128):
+    """(graph, images [B,3,S,S], ids [B,L], labels [B]) for the fused model.  Non-pad tokens per function ~ U[tok_lo, seq_len]
+    (tok_lo = seq_len: every function fills its row)."""
     graphs = [make_graph(i, n_lo, n_hi, salt=salt) for i in indices]
     g = batch_graphs(graphs)
     images = torch.stack([make_image(i, img_size, salt) for i in indices])
-    ids = torch.stack([make_ids(i, seq_len, vocab, salt=salt) for i in indices])
+    ids = torch.stack([make_ids(i, seq_len, vocab, lo=tok_lo, salt=salt) for i in indices])
     labels = torch.tensor([make_label(i, salt) for i in indices], dtype=torch.int64)
     return g, images, ids, labels
