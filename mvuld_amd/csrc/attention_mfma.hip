@@ -425,51 +425,67 @@ __global__ __launch_bounds__(256) void attn_delta_k(const bf16* __restrict__ out
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
 // one block of NT key tiles: dS^T = P^T o (dP^T - delta), dQ^T += K^T . dS^T   (scores in log2 units, gradients in natural units)
-template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = false>
+// QT query tiles per wave share every LDS read of the block -- the K and V fragments of the two score products and the transposed
+// K operand of the dQ product (the passes are LDS-bound: section 9b of DESIGN.md); only the bias words are per (query, key).
+template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = false, int QT = 1>
 __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
-                                            const bf16x8_t (&qf)[HD / 32], const bf16x8_t (&dof)[HD / 32], const char* tabq, int regq, int vq,
-                                            float L2q, const f32x4_t& negD, int lane, f32x4_t (&dq)[HD / 16], unsigned ebase = 0,
-                                            unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
+                                            const bf16x8_t (&qf)[QT][HD / 32], const bf16x8_t (&dof)[QT][HD / 32], const char* const (&tabq)[QT],
+                                            const int (&regq)[QT], const int (&vq)[QT], const float (&L2q)[QT], const f32x4_t (&negD)[QT],
+                                            int lane, f32x4_t (&dq)[QT][HD / 16], const unsigned (&ebase)[QT], unsigned dseed = 0,
+                                            unsigned dthr = 0, float dinv = 1.f) {
     const int fc = lane & 15, fg = lane >> 4;
-    f32x4_t s[NT], dp[NT];
+    f32x4_t s[QT][NT], dp[QT][NT];
     int ki[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
         ki[t][0] = inf.x; ki[t][1] = inf.y; ki[t][2] = inf.z; ki[t][3] = inf.w;
-        s[t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq);       // bias and -delta are accumulator inits, not VALU ops
-        dp[t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : negD;         // with dropout the mask sits between dO.V^T and -delta
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            s[q][t] = am_bias4<MODE, MASK, TAIL, G4>(ki[t], tabq[q]);   // bias and -delta are accumulator inits, not VALU ops
+            dp[q][t] = DROP ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : negD[q];    // with dropout the mask sits between dO.V^T and -delta
+        }
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             const int o = am_off<HD, HD == 32>(kb + 16 * t + fc, ks * 4 + fg);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Ks + o), qf[ks], s[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(Vs + o), dof[ks], dp[t], 0, 0, 0);
+            const bf16x8_t kfr = *(const bf16x8_t*)(Ks + o), vfr = *(const bf16x8_t*)(Vs + o);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                s[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[q][ks], s[q][t], 0, 0, 0);
+                dp[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[q][ks], dp[q][t], 0, 0, 0);
+            }
         }
     }
-    u32x4_t dsw[NT / 2];
-    const f32x2_t L2 = {L2q, L2q};
+    u32x4_t dsw[QT][NT / 2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int q = 0; q < QT; ++q) {
+        const f32x2_t L2 = {L2q[q], L2q[q]};
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
-            f32x2_t sv = {s[t][2 * hp], s[t][2 * hp + 1]}, dpv = {dp[t][2 * hp], dp[t][2 * hp + 1]};
-            if (MODE != 0 || MASK || TAIL) {                      // padding keys -> NEG_BIG -> p = 0
-                sv[0] = am_mask<MODE, MASK, TAIL>(sv[0], ki[t][2 * hp], regq, vq);
-                sv[1] = am_mask<MODE, MASK, TAIL>(sv[1], ki[t][2 * hp + 1], regq, vq);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                f32x2_t sv = {s[q][t][2 * hp], s[q][t][2 * hp + 1]}, dpv = {dp[q][t][2 * hp], dp[q][t][2 * hp + 1]};
+                if (MODE != 0 || MASK || TAIL) {                      // padding keys -> NEG_BIG -> p = 0
+                    sv[0] = am_mask<MODE, MASK, TAIL>(sv[0], ki[t][2 * hp], regq[q], vq[q]);
+                    sv[1] = am_mask<MODE, MASK, TAIL>(sv[1], ki[t][2 * hp + 1], regq[q], vq[q]);
+                }
+                if (DROP) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        dpv[e] = (am_keep(ebase[q] + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? dpv[e] * dinv : 0.f) + negD[q][0];
+                }
+                dsw[q][t >> 1][(t & 1) * 2 + hp] = am_pk(am_exp2(sv - L2) * dpv);
             }
-            if (DROP) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    dpv[e] = (am_keep(ebase + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? dpv[e] * dinv : 0.f) + negD[0];
-            }
-            dsw[t >> 1][(t & 1) * 2 + hp] = am_pk(am_exp2(sv - L2) * dpv);
-        }
+    }
 #pragma unroll
     for (int d = 0; d < HD / 16; ++d)
 #pragma unroll
-        for (int pr = 0; pr < NT / 2; ++pr)
-            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_tr<HD>(Ks, d * 16, kb + 32 * pr, lane), __builtin_bit_cast(bf16x8_t, dsw[pr]),
-                                                            dq[d], 0, 0, 0);
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            const bf16x8_t kt = read_tr<HD>(Ks, d * 16, kb + 32 * pr, lane);
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+                dq[q][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, __builtin_bit_cast(bf16x8_t, dsw[q][pr]), dq[q][d], 0, 0, 0);
+        }
 }
 
 template <int HD, int MODE, bool MASK>
@@ -518,24 +534,41 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
     const bool g4 = MODE == 0 && (g.ws & 3) == 0;
-    for (int qt = part + qsplit * wave; qt < ntile; qt += qsplit * (blockDim.x >> 6)) {
-        const int nq = qt * 16 + fc;
-        const bool qok = nq < g.N;
-        const int nqc = qok ? nq : g.N - 1;
-        const int64_t tq = am_token(g, b, w, nqc);
-        const int qinf = am_info(g, valid, b, w, nqc);
-        const char* tabq = (const char*)tab + 4 * (C0 - (qinf & 0xffff));
-        const int regq = (qinf >> 16) & 0xff, vq = qinf;
-        bf16x8_t qf[HD / 32], dof[HD / 32];
-        {
+    // MODE 0 (hd = 32 windows): two query tiles per wave and 32-key blocks; the text encoder keeps one tile and 64-key blocks
+    // (its K/V image at hd = 64 leaves no registers for a second tile's accumulators)
+    constexpr int QT = (MODE == 0 && HD == 32) ? 2 : 1;
+    const int nitem = (ntile + QT - 1) / QT;
+    const int nfull32 = (g.N / 32) * 32;
+    for (int item = part + qsplit * wave; item < nitem; item += qsplit * (blockDim.x >> 6)) {
+        bool qok[QT], tok[QT];
+        int nqc[QT], regq[QT], vq[QT];
+        int64_t tq[QT];
+        const char* tabq[QT];
+        float L2q[QT];
+        f32x4_t negD[QT];
+        unsigned eb[QT];
+        bf16x8_t qf[QT][HD / 32], dof[QT][HD / 32];
+        f32x4_t dq[QT][HD / 16];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const int qt = item * QT + q;
+            tok[q] = qt < ntile;                                   // wave-uniform: an odd tile count leaves the last slot empty
+            const int nq = (tok[q] ? qt : ntile - 1) * 16 + fc;
+            qok[q] = tok[q] && nq < g.N;
+            nqc[q] = nq < g.N ? nq : g.N - 1;
+            tq[q] = am_token(g, b, w, nqc[q]);
+            const int qinf = am_info(g, valid, b, w, nqc[q]);
+            tabq[q] = (const char*)tab + 4 * (C0 - (qinf & 0xffff));
+            regq[q] = (qinf >> 16) & 0xff;
+            vq[q] = qinf;
             float f[HD / 32][8];
             float ss = 0.f;
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
                 U8 x, y;
-                x.u = *(const uint4*)(qkv + tq * rs + h * HD + ks * 32 + fg * 8);
-                y.u = qok ? *(const uint4*)(dout + tq * C + h * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
-                dof[ks] = y.v;
+                x.u = *(const uint4*)(qkv + tq[q] * rs + h * HD + ks * 32 + fg * 8);
+                y.u = qok[q] ? *(const uint4*)(dout + tq[q] * C + h * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
+                dof[q][ks] = y.v;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
             }
@@ -544,67 +577,77 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)(f[ks][e] * sc);
-            if (MODE == 0 && qt_out && qok) {          // q~ * log2(e), re-used by the bias-table gradient pass
+                for (int e = 0; e < 8; ++e) qf[q][ks][e] = (bf16)(f[ks][e] * sc);
+            if (MODE == 0 && qt_out && qok[q]) {          // q~ * log2(e), re-used by the bias-table gradient pass
 #pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) { U8 o; o.v = qf[ks]; *(uint4*)(qt_out + tq * C + h * HD + ks * 32 + fg * 8) = o.u; }
+                for (int ks = 0; ks < HD / 32; ++ks) { U8 o; o.v = qf[q][ks]; *(uint4*)(qt_out + tq[q] * C + h * HD + ks * 32 + fg * 8) = o.u; }
             }
-        }
-        const float L2q = lse[lse0 + nqc] * LOG2E;
-        const float Dq = qok ? delta[tq * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
-        const f32x4_t negD = {-Dq, -Dq, -Dq, -Dq};
-        f32x4_t dq[HD / 16];
+            L2q[q] = lse[lse0 + nqc[q]] * LOG2E;
+            const float Dq = qok[q] ? delta[tq[q] * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
+            negD[q] = (f32x4_t){-Dq, -Dq, -Dq, -Dq};
+            eb[q] = ((unsigned)lse0 + (unsigned)nqc[q]) * NL;
 #pragma unroll
-        for (int d = 0; d < HD / 16; ++d) dq[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < HD / 16; ++d) dq[q][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
         int kb = 0;
-        if (MODE == 1 && drop) {
-            const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;
-            for (; kb < nfull64; kb += 64)
-                am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
-            for (; kb < Np; kb += 32)
-                am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
-        } else if (g4) {
-            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
-            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
-        } else {
-            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, false>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
-            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq);
-        }
-        // dq[d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
-        if (MODE == 0) {
-            float qh[HD / 16][4];
-            float ss = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d) {
-                U4 x;
-                x.u = *(const uint2*)(qkv + tq * rs + h * HD + d * 16 + 4 * fg);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { qh[d][r] = (float)x.e[r]; ss += qh[d][r] * qh[d][r]; }
+        if (QT == 2) {
+            if (g4) {
+                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MASK, false, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+            } else {
+                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MASK, false, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
             }
-            const float qinv = 1.0f / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
-            float dot = 0.f;
+        } else if (MODE == 1 && drop) {
+            for (; kb < nfull64; kb += 64)
+                am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
+            for (; kb < Np; kb += 32)
+                am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
+        } else if (g4) {
+            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+        } else {
+            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+        }
+        // dq[q][d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
 #pragma unroll
-            for (int d = 0; d < HD / 16; ++d)
+        for (int q = 0; q < QT; ++q) {
+            if (MODE == 0) {
+                float qh[HD / 16][4];
+                float ss = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { qh[d][r] *= qinv; dot += dq[d][r] * qh[d][r]; }
-            if (qok) dtau_part += dot;
-            dot = sum4g(dot) * tau;                   // q^ . d(q^)
-            if (qok) {
+                for (int d = 0; d < HD / 16; ++d) {
+                    U4 x;
+                    x.u = *(const uint2*)(qkv + tq[q] * rs + h * HD + d * 16 + 4 * fg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qh[d][r] = (float)x.e[r]; ss += qh[d][r] * qh[d][r]; }
+                }
+                const float qinv = 1.0f / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+                float dot = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD / 16; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { qh[d][r] *= qinv; dot += dq[q][d][r] * qh[d][r]; }
+                if (qok[q]) dtau_part += dot;
+                dot = sum4g(dot) * tau;                   // q^ . d(q^)
+                if (qok[q]) {
+#pragma unroll
+                    for (int d = 0; d < HD / 16; ++d) {
+                        U4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o.e[r] = (bf16)((tau * dq[q][d][r] - qh[d][r] * dot) * qinv);
+                        *(uint2*)(dqkv + tq[q] * rs + h * HD + d * 16 + 4 * fg) = o.u;
+                    }
+                }
+            } else if (qok[q]) {
 #pragma unroll
                 for (int d = 0; d < HD / 16; ++d) {
                     U4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o.e[r] = (bf16)((tau * dq[d][r] - qh[d][r] * dot) * qinv);
-                    *(uint2*)(dqkv + tq * rs + h * HD + d * 16 + 4 * fg) = o.u;
+                    for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(dq[q][d][r] * g.scale);
+                    *(uint2*)(dqkv + tq[q] * rs + h * HD + d * 16 + 4 * fg) = o.u;
                 }
-            }
-        } else if (qok) {
-#pragma unroll
-            for (int d = 0; d < HD / 16; ++d) {
-                U4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(dq[d][r] * g.scale);
-                *(uint2*)(dqkv + tq * rs + h * HD + d * 16 + 4 * fg) = o.u;
             }
         }
     }
