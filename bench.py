@@ -223,6 +223,41 @@ def main():
                   "unit": "functions/s", "ms_per_step": round(dtv / args.steps * 1e3, 3)}
         ids, lens = main_ids, main_lens
 
+    # The same step fed from HOST memory, as main_bigvul.py's loop hands batches over (collated batch in pinned memory ->
+    # model_step_inputs: asynchronous H2D of 32 x 2.4 MB of images + ids + graph, lengths counted on the host): the PCIe-inclusive
+    # rate.  Reported beside the headline; `value` keeps its inputs resident in HBM, as the contract asks.
+    host_fed = None
+    if world_size() == 1 and not args.no_varlen:
+        from mvuld_amd.data import synthetic as _syn
+        from mvuld_amd.main_bigvul import model_step_inputs
+        f_ = config.FUSED
+        hb = []
+        for k in range(2):
+            gh, ih, dh, lh = _syn.make_batch([1000 * (k + 1) + i for i in range(args.batch)], config.DATA.IMG_SIZE, f_.SEQ_LEN, f_.TEXT.VOCAB,
+                                             f_.NODES_LO, f_.NODES_HI, tok_lo=f_.SEQ_LEN)
+            gh.index()
+            hb.append((gh, ih.pin_memory(), dh.pin_memory(), lh.pin_memory()))
+        keep = (g, images, ids, labels, lens)
+        n_h = [0]
+
+        def step_host():
+            nonlocal g, images, ids, labels, lens
+            g, images, ids, labels, kw = model_step_inputs(hb[n_h[0] % 2], device)
+            lens = kw.get("seq_lens")
+            n_h[0] += 1
+            return step()
+        for _ in range(max(2, args.warmup)):
+            step_host()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_host()
+        fence()
+        dth = time.perf_counter() - t0
+        host_fed = {"value": round(args.batch * args.steps / dth, 3), "unit": "functions/s", "ms_per_step": round(dth / args.steps * 1e3, 3),
+                    "h2d_MB_per_step": round(sum(t.numel() * t.element_size() for t in hb[0][1:]) / 1e6, 1)}
+        g, images, ids, labels, lens = keep
+
     roofline = None
     if not args.no_kernel_timing:
         hip.TIMING.enable()
@@ -262,7 +297,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_ms if graphed is not None else host_unthrottled_ms, 3),
                        "host_enqueue_eager_ms_per_step": round(host_unthrottled_ms, 2),
                        "text_tokens_nonpad_frac": round(float(lens.sum()) / ids.numel(), 4), "final_loss": round(loss_val, 5)},
-            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "varlen_text": varlen,
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "varlen_text": varlen, "host_fed_inputs": host_fed,
         }
         print(json.dumps(out))
     if world_size() > 1:

@@ -57,7 +57,7 @@ def gather_cat(t: torch.Tensor) -> torch.Tensor:
 
 
 def broadcast_parameters(flat: torch.Tensor, src=0):
-    if world_size() > 1:
+    if world_size() > 1 or (os.environ.get("MVULD_FORCE_ALLREDUCE", "0") == "1" and dist.is_available() and dist.is_initialized()):
         dist.broadcast(flat, src)
 
 
@@ -72,7 +72,7 @@ def attach_gradient_exchange(store, max_bucket_elems=64 * 1024 * 1024):
     store.grad_scale = 1.0 / world_size()
     tags = [f"swin.layers.{i}" for i in range(4)] + ["unixcoder"]
     for tag in tags:
-        if world_size() > 1:
+        if reducer._active():
             ops.on_backward_done(tag, lambda tag=tag: reducer.launch_ranges(store.segment(tag + ".")), key="grad-exchange")
         else:
             ops.on_backward_done(tag, None, key="grad-exchange")
@@ -87,6 +87,11 @@ class GradAllReducer:
         self.max_bucket = max_bucket_elems
         self.pending = []
         self.done = []            # [(start, end)] already launched this step
+        # a single-rank process group still runs every collective when forced: lets a one-GPU box execute the RCCL path end to end
+        self.force = os.environ.get("MVULD_FORCE_ALLREDUCE", "0") == "1"
+
+    def _active(self):
+        return world_size() > 1 or (self.force and dist.is_available() and dist.is_initialized())
 
     def _launch(self, a, b):
         while a < b:
@@ -97,7 +102,7 @@ class GradAllReducer:
 
     def launch_ranges(self, ranges):
         """Start the exchange of finished ranges (called from inside backward)."""
-        if world_size() == 1:
+        if not self._active():
             return
         for a, b in ranges:
             self._launch(a, b)
@@ -106,8 +111,7 @@ class GradAllReducer:
     def finish(self):
         """Exchange everything not yet launched and wait.  The buffer then holds SUMS over ranks: the 1/world factor
         is folded into the clip coefficient the AdamW kernel applies (ParamStore.clip_grad_norm_(grad_scale=1/world))."""
-        ws = world_size()
-        if ws == 1:
+        if not self._active():
             return
         if self.g.is_cuda:
             from . import ops
