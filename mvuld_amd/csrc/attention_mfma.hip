@@ -681,7 +681,7 @@ __device__ __forceinline__ float dpp_row(float v) {
 // entry of a register is loop invariant between the two switches of a dy, so dS accumulates in registers; a flush folds the
 // 4-register diagonals of a lane row with DPP shifts before the LDS atomics (3x fewer of them).
 template <int HD, int G>
-__global__ __launch_bounds__(512) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
+__global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
                                                              const float* __restrict__ table16, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              float* __restrict__ dtable16, float* __restrict__ part_out, int Npad, int split) {
@@ -1224,14 +1224,23 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     if (mode == 0 && (passes & 2)) {
         MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
         const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
-        constexpr int DG = 4;                                   // dy per work item: ws = 28 -> 7 groups x 2 q parts = 14 items / 8 waves
+        // dy per work item: 4 (ws = 28 -> 7 groups x 2 q parts = 14 items on 8 waves, 250 VGPRs) or 2 (28 items on 16 waves, 128 VGPRs)
+        static int dbias_g = 0;
+        if (!dbias_g) { const char* e = getenv("MVULD_ATTN_DBIAS_G"); dbias_g = e ? atoi(e) : 4; }
+        const int DG = dbias_g == 2 ? 2 : 4;
         const int items = ((ws + DG - 1) / DG) * ((ws + 15) / 16);
         int sp = 1;
         while ((int64_t)B * nW * H * sp < 256 && sp * 2 <= items) sp *= 2;
         float* part = (ws_part && ws_part_bytes >= (int64_t)B * nW * H * sp * T2 * 4) ? ws_part : nullptr;
-        if (am_set_lds(attn_bwd_dbias_mfma_k<32, DG>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, DG>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv,
-                           (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
+        if (DG == 4) {
+            if (am_set_lds(attn_bwd_dbias_mfma_k<32, 4>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
+            hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, 4>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv,
+                               (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
+        } else {
+            if (am_set_lds(attn_bwd_dbias_mfma_k<32, 2>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
+            hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, 2>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv,
+                               (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
+        }
         if (part)
             hipLaunchKernelGGL(attn_dbias_reduce_k, dim3(cdiv(T2, 256), H, max(1, min(16, B * nW * sp / 8))), dim3(256), 0, stream, part, dtable16, T2, H,
                                B * nW, sp);
