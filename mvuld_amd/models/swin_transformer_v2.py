@@ -138,7 +138,14 @@ class _SwinBlockFn(torch.autograd.Function):
         ops.linear_wgrad(dproj, att, a.proj.weight, a.proj.bias)
         datt = ops.gemm_nt(dproj, ops.weight_t(a.proj.weight, ad))
         T2 = table16.shape[0]
-        dtable = torch.zeros((T2, H), dtype=torch.float32, device=x.device)
+        # zeroed accumulators of the two passes that run on the weight-gradient stream (bias-table gradient, q/v-bias column sums):
+        # ONE fill, issued on that stream -- not on the critical chain of data-gradient kernels
+        wgs = ops.wgrad_stream_for_current()
+        if wgs is not None and not ops._mfma_attn_ok(geom, qkv.dtype):
+            wgs = None                            # the VALU attention backward accumulates the table gradient on THIS stream
+        with torch.cuda.stream(wgs if wgs is not None else torch.cuda.current_stream(x.device)):
+            zbuf = torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
+        dtable = zbuf[:T2 * H].view(T2, H)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
                             ops.grad_of(a.logit_scale).view(-1))
         bst = ops.BIAS_STREAM[0]                  # where attn_bwd left dtable (the weight-gradient stream when one is active)
@@ -152,7 +159,7 @@ class _SwinBlockFn(torch.autograd.Function):
         if a.q_bias is not None:
             # q_bias / v_bias gradients = column sums of dqkv: taken from the weight-gradient kernel's fused column sum (one
             # [3C] scratch, two slice adds) instead of two more passes over dqkv
-            dqb = torch.zeros(3 * C, dtype=torch.float32, device=x.device)
+            dqb = zbuf[T2 * H:]
             st = ops.linear_wgrad(dqkv, x, a.qkv.weight, None, bias_out=dqb)
             with torch.cuda.stream(st):                                 # the stream of the kernel that filled dqb
                 ops.grad_of(a.q_bias).add_(dqb[:C])
