@@ -268,6 +268,18 @@ int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, fl
  * the per-iteration cosine learning rate and the bias corrections of a hipGraph-captured step, refreshed by a small copy before
  * each replay. */
 
+/* Image ingestion on the device -- the reference's evaluation transform, data/build.py:146-168:
+ *   transforms.Resize((S, S), bicubic) [= PIL.Image.resize, Pillow Resample.c] -> ToTensor -> Normalize(mean, std).
+ * images [B][H][W][3] uint8 RGB -> out [B][3][Ho][Wo] fp32 / bf16, bit-exact with Pillow's two-pass 8-bit resampler (uint8 rounding
+ * after each pass).  bounds_h / kk_h (horizontal) and bounds_v / kk_v (vertical): Pillow's precompute_coeffs + normalize_coeffs_8bpc
+ * tables for the axis (int32 [n_out][2] = first tap, tap count; int32 [n_out][ksize] 22-bit fixed point), built on the host
+ * (mvuld_amd/data/image_ingest.py).  bounds_h == NULL skips the horizontal pass (W == Wo, as Pillow does).  tmp: B*H*Wo*3 bytes.
+ * u8_out (optional, [B][Ho][Wo][3]): the resized 8-bit image itself. */
+int mvuld_image_resize_bicubic_normalize(const void* images, int B, int H, int W, const int* bounds_h, const int* kk_h, int ksize_h,
+                                         const int* bounds_v, const int* kk_v, int ksize_v, int Ho, int Wo, void* tmp, void* out,
+                                         int out_dtype, void* u8_out, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b,
+                                         mvuld_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

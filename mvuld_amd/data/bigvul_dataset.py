@@ -41,7 +41,9 @@ def collate(samples):
     gs, a, b, y = zip(*samples)
     g = batch_graphs(list(gs))
     g.index()          # CSR by destination / by source built here, on the loader's CPU side: BatchedGraph.to() carries it to the device
-    return g, torch.stack(a), torch.stack(b), torch.tensor(y, dtype=torch.int64)
+    # decoded images may arrive as uint8 [H, W, 3] of any size (device-side resize + normalise: data/image_ingest.py): kept as a list
+    imgs = list(a) if a[0].dtype == torch.uint8 else torch.stack(a)
+    return g, imgs, torch.stack(b), torch.tensor(y, dtype=torch.int64)
 
 
 def _world():

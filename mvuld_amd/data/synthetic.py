@@ -84,6 +84,11 @@ def make_label(index: int, salt=0) -> int:
     return int(synth.unit(f"label/{index}", 1, salt)[0] > 0)
 
 
+def make_image_u8(index: int, h: int, w: int, salt=0) -> torch.Tensor:
+    """A decoded RGB image as the loader would hand it over: uint8 [h, w, 3] (deterministic per index)."""
+    return synth.ints(f"img8/{index}", (h, w, 3), 0, 256, salt).to(torch.uint8)
+
+
 def make_batch(indices, img_size=448, seq_len=512, vocab=51416, n_lo=150, n_hi=250, salt=0, tok_lo=128):
     """(graph, images [B,3,S,S], ids [B,L], labels [B]) for the fused model.  Non-pad tokens per function ~ U[tok_lo, seq_len]
     (tok_lo = seq_len: every function fills its row)."""

@@ -104,7 +104,7 @@ def build_fused_model(config):
     return Multi_DefectModel_new_GCN(config=config, act_dtype=ad)
 
 
-def model_step_inputs(batch, device, pad_token_id=1):
+def model_step_inputs(batch, device, pad_token_id=1, image_size=None):
     """Host batch -> device inputs of one step: (g, a, b, target, kwargs).  For the fused model (`b` = token ids) the per-function
     count of non-pad tokens is taken here, while the ids are still on the host: the text encoder then runs pad-free
     (models/unixcoder.py: encode_packed) without a device -> host round trip.  The graph's CSR index rides along (built in collate)."""
@@ -114,7 +114,27 @@ def model_step_inputs(batch, device, pad_token_id=1):
         kw["seq_lens"] = (b != pad_token_id).sum(1).to(torch.int32)
     if g._index is None and not g.src.is_cuda:
         g.index()
-    return g.to(device), a.to(device, non_blocking=True), b.to(device, non_blocking=True), target.to(device, non_blocking=True), kw
+    if isinstance(a, (list, tuple)):
+        a = device_image_transform(a, device, image_size)
+    else:
+        a = a.to(device, non_blocking=True)
+    return g.to(device), a, b.to(device, non_blocking=True), target.to(device, non_blocking=True), kw
+
+
+_IMAGE_TF = {}
+
+
+def device_image_transform(images_u8, device, size):
+    """Decoded RGB images (uint8 [H, W, 3], any sizes, host or device) -> [B, 3, size, size] float32 on the device: the reference's
+    evaluation transform (data/build.py:146-168: PIL bicubic resize, ToTensor, Normalize) run by the HIP kernels of
+    data/image_ingest.py on the raw bytes -- the loader thread only decodes, and the H2D copy moves bytes instead of floats."""
+    from mvuld_amd.data.image_ingest import DeviceImageTransform
+    assert size, "model_step_inputs(..., image_size=config.DATA.IMG_SIZE) is needed for uint8 images"
+    tf = _IMAGE_TF.get(size)
+    if tf is None:
+        tf = _IMAGE_TF[size] = DeviceImageTransform(size)
+    outs = [tf(im.to(device, non_blocking=True).contiguous()) for im in images_u8]       # sizes differ per function: one launch pair each
+    return torch.cat(outs, 0)
 
 
 def myMain(config, args, device):
@@ -205,7 +225,7 @@ def train_one_epoch(config, model, criterion, data_loader, optimizer, epoch, mix
     start = end = time.time()
     acc = max(1, config.TRAIN.ACCUMULATION_STEPS)
     for idx, batch in enumerate(data_loader):
-        g, a, b, targets, kw = model_step_inputs(batch, device)
+        g, a, b, targets, kw = model_step_inputs(batch, device, image_size=config.DATA.IMG_SIZE)
         outputs = model(g, a, b, **kw)
         # CrossEntropyLoss (:298) divided by the accumulation steps (:333); probs = softmax (:330)
         loss, probs = cross_entropy(outputs, targets, loss_scale=1.0 / acc)
@@ -247,7 +267,7 @@ def validate(config, data_loader, model, device):
     outs, probs_all, targets_all = [], [], []
     end = time.time()
     for idx, batch in enumerate(data_loader):
-        g, a, b, targets, kw = model_step_inputs(batch, device)
+        g, a, b, targets, kw = model_step_inputs(batch, device, image_size=config.DATA.IMG_SIZE)
         outputs = model(g, a, b, **kw)
         loss, probs = cross_entropy(outputs, targets)
         outs.append(outputs.float()); probs_all.append(probs.float()); targets_all.append(targets.float())

@@ -430,3 +430,33 @@ def test_fused_model_loads_reference_keyed_files(tmp_path):
     cfg.defrost(); cfg.MODEL.MULTI.RESUME = fh; cfg.EVAL_MODE = True; cfg.freeze()
     um.load_checkpoint(cfg, fused2, None, None, None, logging.getLogger("t"))
     assert torch.equal(fused2.state_dict()["head.gat.fc.weight"], head_sd["gat.fc.weight"])
+
+
+@pytest.mark.parametrize("h,w,S", [(600, 800, 448), (300, 200, 448), (448, 448, 448), (1000, 448, 448), (97, 1301, 448), (448, 900, 224)])
+def test_image_oracle_matches_pillow_bicubic(h, w, S):
+    """oracle/image_ref.py restates Pillow's two-pass fixed-point bicubic resampler (what torchvision's Resize does to the PIL image of
+    build.py:146-168): pinned against PIL.Image.resize itself, byte for byte -- shrinking (antialiased, long tap lists), enlarging,
+    one axis unchanged (that pass is skipped), both unchanged."""
+    from PIL import Image
+    from oracle import image_ref
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    img[: h // 3, :, :] = (np.linspace(0, 255, w)[None, :, None]).astype(np.uint8)        # smooth region next to noise
+    ref = np.asarray(Image.fromarray(img, "RGB").resize((S, S), Image.BICUBIC))
+    mine = image_ref.resize_bicubic_u8(img, S, S)
+    assert np.array_equal(mine, ref)
+    # ToTensor + Normalize in float32 (torchvision's op order)
+    t = torch.from_numpy(ref).permute(2, 0, 1).float().div(255)
+    t = (t - torch.tensor(image_ref.IMAGENET_DEFAULT_MEAN)[:, None, None]) / torch.tensor(image_ref.IMAGENET_DEFAULT_STD)[:, None, None]
+    assert np.array_equal(image_ref.to_tensor_normalize(ref), t.numpy())
+
+
+def test_image_ingest_tap_tables_match_oracle():
+    """The product's host-side tap tables (mvuld_amd/data/image_ingest.py) against the oracle's, exactly, over shrink / enlarge / equal sizes."""
+    from oracle import image_ref
+    from mvuld_amd.data.image_ingest import pillow_bicubic_taps
+    for n_in, n_out in [(800, 448), (200, 448), (448, 448), (1301, 448), (97, 448), (449, 448), (3000, 224)]:
+        b0, k0, s0 = image_ref.precompute_coeffs(n_in, n_out)
+        b1, k1, s1 = pillow_bicubic_taps(n_in, n_out)
+        assert s0 == s1 and np.array_equal(b0, b1) and np.array_equal(k0, k1)
+        assert int(np.abs(k1.sum(1) - (1 << 22)).max()) <= k1.shape[1]           # every row sums to 1.0 in 22-bit fixed point, up to rounding

@@ -1,6 +1,8 @@
 """GPU parity of individual C-ABI kernels against plain PyTorch fp32 on the CPU (sizes: seconds)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -681,3 +683,26 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
     finally:
         ops.USE_TN_SLABS[0] = True
         hip.LIB.fn("mvuld_set_gemm_tn256")(1)
+
+
+@pytest.mark.parametrize("B,h,w,S", [(2, 600, 800, 448), (1, 300, 200, 448), (3, 448, 448, 448), (1, 1000, 448, 448), (2, 97, 1301, 448),
+                                     (1, 448, 900, 224)])
+def test_image_ingest_matches_pillow_restatement(gpu, B, h, w, S):
+    """mvuld_image_resize_bicubic_normalize (data/build.py:146-168 on the device) against the numpy restatement of Pillow's resampler
+    (itself pinned byte for byte against PIL in the CPU suite): the resized 8-bit image must be IDENTICAL, the normalised float
+    tensor equal to ToTensor + Normalize of it; batches, both passes, a skipped horizontal pass, enlarging, bf16 output."""
+    from oracle import image_ref
+    from mvuld_amd.data.image_ingest import DeviceImageTransform
+    rng = np.random.default_rng(B * 1000 + h + w)
+    imgs = rng.integers(0, 256, size=(B, h, w, 3), dtype=np.uint8)
+    imgs[:, : h // 2] = (imgs[:, : h // 2].astype(np.int32) // 8 + np.linspace(0, 220, w)[None, None, :, None]).astype(np.uint8)
+    tf = DeviceImageTransform(S)
+    out, u8 = tf(torch.from_numpy(imgs).to(gpu), return_u8=True)
+    for b in range(B):
+        ref8 = image_ref.resize_bicubic_u8(imgs[b], S, S)
+        assert np.array_equal(u8[b].cpu().numpy(), ref8), f"image {b}: resized bytes differ from Pillow's"
+        want = image_ref.to_tensor_normalize(ref8)
+        assert float(np.abs(out[b].cpu().numpy() - want).max()) <= 2.4e-7           # one ulp at |x| <= 2.7 (fp32 division rounding modes)
+    out16 = DeviceImageTransform(S, out_dtype=torch.bfloat16)(torch.from_numpy(imgs[:1]).to(gpu))
+    assert out16.dtype == torch.bfloat16 and float((out16.float() - out[:1]).abs().max()) <= 2.0 ** -7
+    assert out.shape == (B, 3, S, S)

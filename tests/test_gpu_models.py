@@ -1021,3 +1021,35 @@ def test_graphed_train_step_matches_eager(gpu):
         assert abs(a - b) < 2e-2 * max(1.0, abs(a))
     p1, p2 = m1._mv_store.flat, m2._mv_store.flat
     assert float((p1 - p2).norm() / p1.norm()) < 2e-3
+
+
+def test_fused_step_from_raw_uint8_images(gpu):
+    """SURVEY section 8f row 2 (image half): the loader hands over DECODED images (uint8 [H, W, 3], a different size per function);
+    main_bigvul.model_step_inputs resizes / normalises them on the device (data/image_ingest.py).  The fused model's logits must equal
+    those on the float images the reference's host transform (PIL bicubic resize + ToTensor + Normalize, build.py:146-168) produces."""
+    from PIL import Image
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model, model_step_inputs
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.data.bigvul_dataset import collate
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16"], batch_size=3, local_rank=0))
+    torch.manual_seed(5)
+    model = build_fused_model(config).to(gpu).eval()
+    f, S = config.FUSED, config.DATA.IMG_SIZE
+    sizes = [(S + 37, 2 * S + 5), (S // 2 + 3, S), (S, S)]
+    g, _, ids, labels = synthetic.make_batch([71, 72, 73], S, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    raw = [synthetic.make_image_u8(80 + i, h, w) for i, (h, w) in enumerate(sizes)]
+    mean, std = torch.tensor([0.485, 0.456, 0.406])[:, None, None], torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+    host = torch.stack([(torch.from_numpy(np.asarray(Image.fromarray(r.numpy(), "RGB").resize((S, S), Image.BICUBIC))).permute(2, 0, 1).float().div(255)
+                         - mean) / std for r in raw])
+    from mvuld_amd.graph import unbatch
+    samples = [(gi, r, ids[i], int(labels[i])) for i, (gi, r) in enumerate(zip(unbatch(g), raw))]
+    batch = collate(samples)
+    assert isinstance(batch[1], list) and batch[1][0].dtype == torch.uint8
+    gd, a, b, t, kw = model_step_inputs(batch, gpu, image_size=S)
+    assert a.shape == (3, 3, S, S) and float((a.cpu() - host).abs().max()) <= 2.4e-7
+    with torch.no_grad():
+        l_dev = model(gd, a, b, **kw).float().cpu()
+        l_host = model(g.to(gpu), host.to(gpu), ids.to(gpu)).float().cpu()
+    assert float((l_dev - l_host).abs().max()) < 1e-5
