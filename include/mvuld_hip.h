@@ -60,6 +60,10 @@ int mvuld_set_gemm_256_min_k(int min_k);
  * mvuld_layernorm_fwd_q8: mvuld_layernorm_fwd that also emits y as e4m3 under q_state[0] and folds max|y| into q_state[1].
  * mvuld_fp8_roll_scales: for each of n {scale, amax} pairs: amax > 0 ? (scale = amax / 448, amax = 0) : unchanged. */
 int mvuld_quant_e4m3(const void* x, int64_t n, int dtype, void* out, float* scale_out, float* partials, mvuld_stream_t stream);
+/* the same for many fp32 tensors in three launches (all QKV / FFN weights after an optimizer step).  jobs: device array of
+ * {const float* src; uint8_t* dst; float* scale; int64_t n (% 8 == 0); int64_t blk0 (first of the tensor's ceil(n / 8192) blocks)};
+ * partials: total_blocks floats of scratch. */
+int mvuld_quant_e4m3_batched(const void* jobs, int njobs, int64_t total_blocks, float* partials, mvuld_stream_t stream);
 int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                       const float* bias, int epilogue, void* aux, int64_t ldaux, const float* scale_a, const float* scale_b,
                       void* q_out, int64_t ldq, float* q_state, mvuld_stream_t stream);

@@ -861,3 +861,67 @@ extern "C" int mvuld_fp8_roll_scales(float* state, int n, hipStream_t stream) {
     MV_LAUNCH_CHECK("fp8_roll_scales");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ batched e4m3 quantisation of many fp32 tensors
+// The fp8 forward GEMMs need every QKV / FFN weight requantised after each optimizer step: 102 tensors x (absmax + convert) was 204
+// launches.  One job table (like transpose_batched) and three launches: per-block |x| maxima of all tensors, one block per tensor to
+// fold its maxima into its scale, one conversion pass.  Each block covers Q_CHUNK elements of one tensor.
+struct QuantJob { const float* src; uint8_t* dst; float* scale; int64_t n; int64_t blk0; };
+#define Q_CHUNK 8192
+__device__ __forceinline__ QuantJob q_job_of(const QuantJob* __restrict__ jobs, int njobs, int64_t blk) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return jobs[lo];
+}
+__global__ __launch_bounds__(256) void quant_batched_absmax_k(const QuantJob* __restrict__ jobs, int njobs, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const QuantJob jb = q_job_of(jobs, njobs, blockIdx.x);
+    const int64_t e0 = (blockIdx.x - jb.blk0) * Q_CHUNK, e1 = min(jb.n, e0 + Q_CHUNK);
+    float m = 0.f;
+    for (int64_t i = e0 + threadIdx.x * 4; i < e1; i += 1024) {
+        const float4 v = *(const float4*)(jb.src + i);            // n % 8 == 0 and chunks of 8192: whole float4s
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void quant_batched_scale_k(const QuantJob* __restrict__ jobs, int njobs, const float* __restrict__ partials) {
+    __shared__ float red[4];
+    const QuantJob jb = jobs[blockIdx.x];
+    const int64_t nblk = (jb.n + Q_CHUNK - 1) / Q_CHUNK;
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, partials[jb.blk0 + i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) jb.scale[0] = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-12f) * (1.0f / 448.0f);
+}
+__global__ __launch_bounds__(256) void quant_batched_convert_k(const QuantJob* __restrict__ jobs, int njobs) {
+    const QuantJob jb = q_job_of(jobs, njobs, blockIdx.x);
+    const int64_t e0 = (blockIdx.x - jb.blk0) * Q_CHUNK, e1 = min(jb.n, e0 + Q_CHUNK);
+    const float inv = 1.0f / jb.scale[0];
+    for (int64_t i = e0 + threadIdx.x * 8; i < e1; i += 2048) {
+        const float4 v0 = *(const float4*)(jb.src + i), v1 = *(const float4*)(jb.src + i + 4);
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v0.x * inv, v0.y * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v0.z * inv, v0.w * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v1.x * inv, v1.y * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v1.z * inv, v1.w * inv, hi, true);
+        *(uint2*)(jb.dst + i) = make_uint2(lo, hi);
+    }
+}
+// jobs: device array of {src fp32, dst e4m3, scale fp32[1], n (% 8 == 0), blk0 = first block of the tensor (prefix sum of
+// ceil(n / 8192))}; partials: total_blocks floats of scratch.  Same result as mvuld_quant_e4m3 per tensor.
+extern "C" int mvuld_quant_e4m3_batched(const void* jobs, int njobs, int64_t total_blocks, float* partials, hipStream_t stream) {
+    MV_CHECK_ARG(jobs && partials && njobs > 0 && total_blocks > 0 && total_blocks < 2147483647LL, "quant_e4m3_batched: bad args");
+    hipLaunchKernelGGL(quant_batched_absmax_k, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const QuantJob*)jobs, njobs, partials);
+    hipLaunchKernelGGL(quant_batched_scale_k, dim3(njobs), dim3(256), 0, stream, (const QuantJob*)jobs, njobs, (const float*)partials);
+    hipLaunchKernelGGL(quant_batched_convert_k, dim3((unsigned)total_blocks), dim3(256), 0, stream, (const QuantJob*)jobs, njobs);
+    MV_LAUNCH_CHECK("quant_e4m3_batched");
+    return 0;
+}

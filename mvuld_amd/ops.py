@@ -189,14 +189,41 @@ def quant_fp8(x, out=None, scale=None):
 
 
 def weight_fp8(p):
-    """(e4m3 copy, scale) of a weight [out, in], requantised when the optimizer has stepped (WEIGHT_EPOCH)."""
+    """(e4m3 copy, scale) of a weight [out, in], requantised when the optimizer has stepped (WEIGHT_EPOCH).  Weights that live in a
+    ParamStore are registered on first use and from then on refreshed all together, in three launches, right after the optimizer
+    step (refresh_store_fp8); anything else is requantised here, lazily."""
     c = getattr(p, "_mv_w8", None)
     if c is None or p._mv_w8_epoch != WEIGHT_EPOCH[0]:
         w = p.data if isinstance(p, torch.nn.Parameter) else p
         q, sc = quant_fp8(w.reshape(w.shape[0], -1), *(c or (None, None)))
+        fresh = c is None
         p._mv_w8 = c = (q, sc)
         p._mv_w8_epoch = WEIGHT_EPOCH[0]
+        st = getattr(p, "_mv_store", None)
+        if fresh and st is not None and w.dtype == torch.float32 and w.is_contiguous():
+            reg = st.__dict__.setdefault("_q8jobs", {"list": [], "table": None, "blocks": 0, "partials": None})
+            reg["list"].append((p, w, q, sc))
+            reg["table"] = None
     return c
+
+
+def refresh_store_fp8(store):
+    """Requantise every registered fp8 weight copy of a ParamStore (called right after the epoch moves, like the transposes)."""
+    reg = getattr(store, "_q8jobs", None)
+    if not reg or not reg["list"] or not FP8_FWD[0]:
+        return
+    if reg["table"] is None:
+        rows, b0 = [], 0
+        for _, w, q, sc in reg["list"]:
+            rows.append([w.data_ptr(), q.data_ptr(), sc.data_ptr(), w.numel(), b0])
+            b0 += (w.numel() + 8191) // 8192
+        dev = reg["list"][0][1].device
+        reg["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        reg["blocks"] = b0
+        reg["partials"] = torch.empty(b0, dtype=torch.float32, device=dev)
+    call("quant_e4m3_batched", ptr(reg["table"]), len(reg["list"]), reg["blocks"], ptr(reg["partials"]))
+    for p, *_ in reg["list"]:
+        p._mv_w8_epoch = WEIGHT_EPOCH[0]
 
 
 class Fp8Site:

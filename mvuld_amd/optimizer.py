@@ -77,6 +77,7 @@ class ParamStore:
         ops.bump_weight_epoch()
         if self.flat.is_cuda:
             ops.refresh_store_transposes(self)
+            ops.refresh_store_fp8(self)
 
     def segment(self, prefix):
         """[(start, end)] flat ranges (one per group) covering the parameters whose name starts with `prefix`."""
@@ -147,6 +148,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._clipped = False
         ops.bump_weight_epoch()           # transposed weight copies are stale now: refresh the registered ones together
         ops.refresh_store_transposes(st)
+        ops.refresh_store_fp8(st)
 
     def host_hyper(self):
         """[n_groups, 3] {lr, 1 - b1^t, sqrt(1 - b2^t)} for the NEXT step() (t = steps taken + 1): what dev_hyper must hold before it."""

@@ -291,6 +291,29 @@ def test_fp8_roll_scales(gpu):
     assert st.cpu().tolist() == pytest.approx([1.0, 0.0, 2.0, 0.0, 0.01, 0.0])
 
 
+def test_quant_e4m3_batched_equals_per_tensor(gpu):
+    """mvuld_quant_e4m3_batched (all fp8 weight copies after an optimizer step, three launches) against one mvuld_quant_e4m3 per
+    tensor: same scales, same bytes -- tensors smaller than, equal to and larger than a block chunk, one all-zero."""
+    from mvuld_amd import ops
+    from mvuld_amd.hip import call, ptr
+    g = torch.Generator().manual_seed(29)
+    sizes = [8, 8192, 8200, 3 * 8192, 768 * 3072, 512 * 512]
+    ws = [(torch.randn(n, generator=g) * (0.02 * (i + 1))).to(gpu) for i, n in enumerate(sizes)]
+    ws[3].zero_()
+    qs = [torch.empty(n, dtype=torch.uint8, device=gpu) for n in sizes]
+    scs = [torch.empty(1, dtype=torch.float32, device=gpu) for _ in sizes]
+    rows, b0 = [], 0
+    for w, q, sc in zip(ws, qs, scs):
+        rows.append([w.data_ptr(), q.data_ptr(), sc.data_ptr(), w.numel(), b0])
+        b0 += (w.numel() + 8191) // 8192
+    table = torch.tensor(rows, dtype=torch.int64).to(gpu)
+    partials = torch.empty(b0, dtype=torch.float32, device=gpu)
+    call("quant_e4m3_batched", ptr(table), len(sizes), b0, ptr(partials))
+    for w, q, sc in zip(ws, qs, scs):
+        q1, s1 = ops.quant_fp8(w)
+        assert float(sc) == float(s1) and torch.equal(q, q1)
+
+
 def test_gemm_nt_fp8_rejects_ineligible_shapes(gpu):
     from mvuld_amd import ops, hip
     qa = torch.zeros((300, 128), dtype=torch.uint8, device=gpu)

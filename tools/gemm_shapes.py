@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 from mvuld_amd import hip, ops  # noqa: E402
 
-B = 32
+B = int(os.environ.get("GS_BATCH", 32))
 EPI = {"none": hip.EPI_NONE, "bias": hip.EPI_BIAS, "gelu": hip.EPI_GELU, "dgelu": hip.EPI_MUL_DGELU, "addaux": hip.EPI_ADD_AUX}
 
 
