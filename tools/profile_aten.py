@@ -14,11 +14,11 @@ from mvuld_amd import hip
 hip.LIB.load()
 from mvuld_amd.models.GraphModel import cross_entropy
 config, model, opt, sched, batch = bench.build(a, device, 0)
-g, images, ids, labels = batch
+g, images, ids, labels, lens = batch
 
 
 def step():
-    logits = model(g, images, ids)
+    logits = model(g, images, ids, seq_lens=lens)
     loss, _ = cross_entropy(logits, labels)
     loss.backward()
     opt.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
