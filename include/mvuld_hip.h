@@ -272,6 +272,10 @@ int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, fl
  * the per-iteration cosine learning rate and the bias corrections of a hipGraph-captured step, refreshed by a small copy before
  * each replay. */
 
+/* SwinV2's qkv bias (q_bias, zeros, v_bias) (swin_transformer_v2.py:147-150) for every block in one launch.
+ * jobs: device array of {const float* q_bias; const float* v_bias; float* dst [3C]; int64_t C}. */
+int mvuld_qkv_bias_pack_batched(const void* jobs, int njobs, mvuld_stream_t stream);
+
 /* Image ingestion on the device -- the reference's evaluation transform, data/build.py:146-168:
  *   transforms.Resize((S, S), bicubic) [= PIL.Image.resize, Pillow Resample.c] -> ToTensor -> Normalize(mean, std).
  * images [B][H][W][3] uint8 RGB -> out [B][3][Ho][Wo] fp32 / bf16, bit-exact with Pillow's two-pass 8-bit resampler (uint8 rounding

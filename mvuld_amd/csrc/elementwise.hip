@@ -925,3 +925,20 @@ extern "C" int mvuld_quant_e4m3_batched(const void* jobs, int njobs, int64_t tot
     MV_LAUNCH_CHECK("quant_e4m3_batched");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ SwinV2 qkv bias = (q_bias, 0, v_bias), all blocks at once
+// swin_transformer_v2.py:147-150 concatenates (q_bias, zeros, v_bias) in every forward; the parameters change once per optimizer
+// step, so the 24 packed [3C] buffers are rebuilt by ONE launch after the step instead of two small copies per block on the
+// forward's critical chain of kernels.
+struct QkvBiasJob { const float* q; const float* v; float* dst; int64_t C; };
+__global__ __launch_bounds__(256) void qkv_bias_pack_batched_k(const QkvBiasJob* __restrict__ jobs) {
+    const QkvBiasJob jb = jobs[blockIdx.x];
+    const int C = (int)jb.C;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) jb.dst[i] = i < C ? jb.q[i] : (i < 2 * C ? 0.f : jb.v[i - 2 * C]);
+}
+extern "C" int mvuld_qkv_bias_pack_batched(const void* jobs, int njobs, hipStream_t stream) {
+    MV_CHECK_ARG(jobs && njobs > 0, "qkv_bias_pack_batched: bad args");
+    hipLaunchKernelGGL(qkv_bias_pack_batched_k, dim3(njobs), dim3(256), 0, stream, (const QkvBiasJob*)jobs);
+    MV_LAUNCH_CHECK("qkv_bias_pack_batched");
+    return 0;
+}

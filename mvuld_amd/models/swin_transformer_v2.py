@@ -295,8 +295,12 @@ class SwinTransformerBlock(nn.Module):
         C = self.dim
         if self._qb is None or self._qb.device != device:
             self._qb = torch.zeros(3 * C, dtype=torch.float32, device=device)
-        self._qb[:C].copy_(a.q_bias.data)
-        self._qb[2 * C:].copy_(a.v_bias.data)
+            self._qb_epoch = -1
+            ops.register_qkv_bias(a.q_bias, a.v_bias, self._qb, self)      # store-resident parameters: rebuilt with all the others
+        if self._qb_epoch != ops.WEIGHT_EPOCH[0]:                          # after every optimizer step, in one launch
+            self._qb[:C].copy_(a.q_bias.data)
+            self._qb[2 * C:].copy_(a.v_bias.data)
+            self._qb_epoch = ops.WEIGHT_EPOCH[0]
         return self._qb
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):

@@ -207,6 +207,34 @@ def weight_fp8(p):
     return c
 
 
+def register_qkv_bias(q_bias, v_bias, dst, owner):
+    """A SwinV2 block's packed (q_bias, 0, v_bias) buffer: when the two parameters live in a ParamStore the buffer joins the
+    store's job table and refresh_store_qkv_bias() rebuilds all of them in one launch after each optimizer step."""
+    st = getattr(q_bias, "_mv_store", None)
+    if st is None or getattr(v_bias, "_mv_store", None) is not st or not dst.is_cuda:
+        return
+    reg = st.__dict__.setdefault("_qbjobs", {"list": [], "table": None})
+    reg["list"].append((q_bias, v_bias, dst, owner))
+    reg["table"] = None
+
+
+def refresh_store_qkv_bias(store):
+    reg = getattr(store, "_qbjobs", None)
+    if not reg or not reg["list"]:
+        return
+    live = [(q, v, d, o) for q, v, d, o in reg["list"] if o._qb is d]          # a block that re-made its buffer re-registers it
+    if len(live) != len(reg["list"]):
+        reg["list"], reg["table"] = live, None
+        if not live:
+            return
+    if reg["table"] is None:
+        rows = [[q.data.data_ptr(), v.data.data_ptr(), d.data_ptr(), q.numel()] for q, v, d, _ in reg["list"]]
+        reg["table"] = torch.tensor(rows, dtype=torch.int64).to(reg["list"][0][2].device)
+    call("qkv_bias_pack_batched", ptr(reg["table"]), len(reg["list"]))
+    for _, _, _, o in reg["list"]:
+        o._qb_epoch = WEIGHT_EPOCH[0]
+
+
 def refresh_store_fp8(store):
     """Requantise every registered fp8 weight copy of a ParamStore (called right after the epoch moves, like the transposes)."""
     reg = getattr(store, "_q8jobs", None)

@@ -78,6 +78,7 @@ class ParamStore:
         if self.flat.is_cuda:
             ops.refresh_store_transposes(self)
             ops.refresh_store_fp8(self)
+            ops.refresh_store_qkv_bias(self)
 
     def segment(self, prefix):
         """[(start, end)] flat ranges (one per group) covering the parameters whose name starts with `prefix`."""
@@ -149,6 +150,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ops.bump_weight_epoch()           # transposed weight copies are stale now: refresh the registered ones together
         ops.refresh_store_transposes(st)
         ops.refresh_store_fp8(st)
+        ops.refresh_store_qkv_bias(st)
 
     def host_hyper(self):
         """[n_groups, 3] {lr, 1 - b1^t, sqrt(1 - b2^t)} for the NEXT step() (t = steps taken + 1): what dev_hyper must hold before it."""
