@@ -12,7 +12,7 @@ a = bench.parse()
 dev = torch.device("cuda:0")
 hip.LIB.load()
 config, model, opt, sched, batch = bench.build(a, dev, 0)
-g, images, ids, labels = batch
+g, images, ids, labels, lens = batch
 marks = {}
 
 
@@ -24,7 +24,7 @@ def mark(name):
 
 orig_swin, orig_text, orig_graph = model.swin.forward_features, model.unixcoder.get_xcode_vec, model.head.forward_graph
 model.swin.forward_features = lambda x: (lambda r: (mark("fwd swin done"), r)[1])(orig_swin(x))
-model.unixcoder.get_xcode_vec = lambda x: (lambda r: (mark("fwd text done"), r)[1])(orig_text(x))
+model.unixcoder.get_xcode_vec = lambda x, sl=None: (lambda r: (mark("fwd text done"), r)[1])(orig_text(x, sl))
 model.head.forward_graph = lambda gg: (lambda r: (mark("fwd graph done"), r)[1])(orig_graph(gg))
 ops.on_backward_done("swin", lambda: mark("bwd swin done"), key="diag")
 ops.on_backward_done("swin.layers.2", lambda: mark("bwd swin stage2 done"), key="diag")
@@ -33,7 +33,7 @@ ops.on_backward_done("unixcoder", lambda: mark("bwd text done (side end)"), key=
 
 def step():
     mark("start")
-    logits = model(g, images, ids)
+    logits = model(g, images, ids, seq_lens=lens)
     loss, _ = cross_entropy(logits, labels)
     mark("fwd head done")
     loss.backward()
