@@ -276,6 +276,14 @@ int mvuld_adamw(float* p, float* g, float* m, float* v, void* p16, int64_t n, fl
  * jobs: device array of {const float* q_bias; const float* v_bias; float* dst [3C]; int64_t C}. */
 int mvuld_qkv_bias_pack_batched(const void* jobs, int njobs, mvuld_stream_t stream);
 
+/* CSR index of a batched graph on the device (what DGL builds lazily on the host for GATConv, GraphModel.py:171-176): edges grouped by
+ * destination and by source in edge-id order (stable), and for every edge in by-source order its slot in the by-destination order.
+ * src / dst: int64 [E] device arrays of node ids < N; outputs int32 (indptr_* [N + 1], the others [E]); ws: scratch of
+ * mvuld_graph_csr_workspace_bytes(E) bytes.  Identical to the host builder mvuld_amd/graph.py: BatchedGraph.index. */
+int64_t mvuld_graph_csr_workspace_bytes(int E);
+int mvuld_graph_csr_build(const int64_t* src, const int64_t* dst, int E, int N, int* indptr_dst, int* src_by_dst, int* indptr_src,
+                          int* dst_by_src, int* slot_by_src, void* ws, int64_t ws_bytes, mvuld_stream_t stream);
+
 /* Image ingestion on the device -- the reference's evaluation transform, data/build.py:146-168:
  *   transforms.Resize((S, S), bicubic) [= PIL.Image.resize, Pillow Resample.c] -> ToTensor -> Normalize(mean, std).
  * images [B][H][W][3] uint8 RGB -> out [B][3][Ho][Wo] fp32 / bf16, bit-exact with Pillow's two-pass 8-bit resampler (uint8 rounding

@@ -68,9 +68,30 @@ class BatchedGraph:
             g._index = {k: v.to(device, non_blocking=non_blocking) for k, v in self._index.items()}
         return g
 
+    def _index_on_device(self):
+        """The same structures built by the library on the graph's device (mvuld_graph_csr_build: stable radix sorts + gathers): no
+        device -> host round trip when a graph reaches the GPU without an index."""
+        from . import hip
+        from .hip import call, ptr
+        n, e, dev = self._n, self.num_edges(), self.src.device
+        src = self.src.to(torch.int64).contiguous()
+        dst = self.dst.to(torch.int64).contiguous()
+        out = {k: torch.empty(n + 1 if k.startswith("indptr") else e, dtype=torch.int32, device=dev)
+               for k in ("indptr_dst", "src_by_dst", "indptr_src", "dst_by_src", "slot_by_src")}
+        nb = hip.LIB.fn("mvuld_graph_csr_workspace_bytes")(e)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        call("graph_csr_build", ptr(src), ptr(dst), e, n, ptr(out["indptr_dst"]), ptr(out["src_by_dst"]), ptr(out["indptr_src"]),
+             ptr(out["dst_by_src"]), ptr(out["slot_by_src"]), ptr(ws), nb)
+        off = torch.zeros(self.batch_size + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(self._batch_num_nodes, 0)
+        out["node_offsets"] = off.to(torch.int32).to(dev, non_blocking=True)
+        return out
+
     # ---- index structures for the kernels -------------------------------
     def index(self):
         """dict of int32 tensors on the graph's device (built once, cached)."""
+        if self._index is None and self.src.is_cuda and self.num_edges() > 0:
+            self._index = self._index_on_device()
         if self._index is None:
             n = self._n
             src, dst = self.src.cpu(), self.dst.cpu()

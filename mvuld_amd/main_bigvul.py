@@ -107,18 +107,66 @@ def build_fused_model(config):
 def model_step_inputs(batch, device, pad_token_id=1, image_size=None):
     """Host batch -> device inputs of one step: (g, a, b, target, kwargs).  For the fused model (`b` = token ids) the per-function
     count of non-pad tokens is taken here, while the ids are still on the host: the text encoder then runs pad-free
-    (models/unixcoder.py: encode_packed) without a device -> host round trip.  The graph's CSR index rides along (built in collate)."""
+    (models/unixcoder.py: encode_packed) without a device -> host round trip.  The graph's CSR index is built on the device from the
+    edge lists (no host sort, no device -> host copy)."""
     g, a, b, target = batch
     kw = {}
     if b.dtype == torch.int64 and b.dim() == 2 and not b.is_cuda:
         kw["seq_lens"] = (b != pad_token_id).sum(1).to(torch.int32)
-    if g._index is None and not g.src.is_cuda:
-        g.index()
+    g = g.to(device)
+    g.index()                   # on the device (mvuld_graph_csr_build) unless the loader already built it on the host
     if isinstance(a, (list, tuple)):
         a = device_image_transform(a, device, image_size)
     else:
         a = a.to(device, non_blocking=True)
-    return g.to(device), a, b.to(device, non_blocking=True), target.to(device, non_blocking=True), kw
+    return g, a, b.to(device, non_blocking=True), target.to(device, non_blocking=True), kw
+
+
+def _record_on(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_on(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_on(v, stream)
+    elif hasattr(obj, "ndata"):                      # BatchedGraph
+        _record_on([obj.src, obj.dst, obj.ndata, obj.edata, obj._index or {}], stream)
+
+
+def device_batches(loader, device, pad_token_id=1, image_size=None):
+    """Iterate `loader` one batch AHEAD of the consumer: while step i computes, batch i+1 goes through model_step_inputs (H2D copies,
+    device CSR index, device image transform) on a copy stream; the consumer's stream only waits for an event.  Yields what
+    model_step_inputs returns.  (train_one_epoch :308-313 copies every batch synchronously at the top of the step.)"""
+    if not (torch.cuda.is_available() and torch.device(device).type == "cuda"):
+        for batch in loader:
+            yield model_step_inputs(batch, device, pad_token_id, image_size)
+        return
+    copy = torch.cuda.Stream(device=device)
+
+    def load(batch):
+        with torch.cuda.stream(copy):
+            out = model_step_inputs(batch, device, pad_token_id, image_size)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        return out, ev
+    it = iter(loader)
+    try:
+        nxt = load(next(it))
+    except StopIteration:
+        return
+    while nxt is not None:
+        cur, ev = nxt
+        main = torch.cuda.current_stream(device)
+        main.wait_event(ev)
+        _record_on(cur, main)
+        try:
+            nxt = load(next(it))                                    # issued before the consumer enqueues step i: overlaps with it
+        except StopIteration:
+            nxt = None
+        yield cur
 
 
 _IMAGE_TF = {}
@@ -224,8 +272,7 @@ def train_one_epoch(config, model, criterion, data_loader, optimizer, epoch, mix
     batch_time, loss_meter, norm_meter, scaler_meter = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     start = end = time.time()
     acc = max(1, config.TRAIN.ACCUMULATION_STEPS)
-    for idx, batch in enumerate(data_loader):
-        g, a, b, targets, kw = model_step_inputs(batch, device, image_size=config.DATA.IMG_SIZE)
+    for idx, (g, a, b, targets, kw) in enumerate(device_batches(data_loader, device, image_size=config.DATA.IMG_SIZE)):
         outputs = model(g, a, b, **kw)
         # CrossEntropyLoss (:298) divided by the accumulation steps (:333); probs = softmax (:330)
         loss, probs = cross_entropy(outputs, targets, loss_scale=1.0 / acc)
@@ -266,8 +313,7 @@ def validate(config, data_loader, model, device):
     batch_time, loss_meter, acc1_meter = AverageMeter(), AverageMeter(), AverageMeter()
     outs, probs_all, targets_all = [], [], []
     end = time.time()
-    for idx, batch in enumerate(data_loader):
-        g, a, b, targets, kw = model_step_inputs(batch, device, image_size=config.DATA.IMG_SIZE)
+    for idx, (g, a, b, targets, kw) in enumerate(device_batches(data_loader, device, image_size=config.DATA.IMG_SIZE)):
         outputs = model(g, a, b, **kw)
         loss, probs = cross_entropy(outputs, targets)
         outs.append(outputs.float()); probs_all.append(probs.float()); targets_all.append(targets.float())

@@ -729,3 +729,26 @@ def test_image_ingest_matches_pillow_restatement(gpu, B, h, w, S):
     out16 = DeviceImageTransform(S, out_dtype=torch.bfloat16)(torch.from_numpy(imgs[:1]).to(gpu))
     assert out16.dtype == torch.bfloat16 and float((out16.float() - out[:1]).abs().max()) <= 2.0 ** -7
     assert out.shape == (B, 3, S, S)
+
+
+@pytest.mark.parametrize("sizes,deg", [([5, 1, 9], 3), ([200] * 32, 4), ([150, 250, 1, 77] * 64, 5)])
+def test_graph_csr_index_on_device_equals_host(gpu, sizes, deg):
+    """mvuld_graph_csr_build (stable radix sorts + gathers on the device) against the host builder BatchedGraph.index(): the six
+    index arrays must be IDENTICAL -- including the edge order inside every destination / source group (edge-id order), which the
+    GAT kernels' deterministic accumulation relies on.  Batches of 3, 32 and 256 graphs; isolated nodes; self loops; multi-edges."""
+    from mvuld_amd.graph import BatchedGraph, add_self_loop
+    gen = torch.Generator().manual_seed(len(sizes) * 31 + deg)
+    srcs, dsts, off = [], [], 0
+    for n in sizes:
+        m = n * deg
+        srcs.append(torch.randint(0, n, (m,), generator=gen) + off)
+        dsts.append(torch.randint(0, max(1, n - 1), (m,), generator=gen) + off)        # the last node of each graph: no in-edges
+        off += n
+    g = add_self_loop(BatchedGraph(torch.cat(srcs), torch.cat(dsts), sizes))
+    host = g.index()
+    gd = BatchedGraph(g.src.to(gpu), g.dst.to(gpu), sizes)
+    assert gd._index is None
+    dev = gd.index()
+    assert set(dev) == set(host)
+    for k in host:
+        assert dev[k].dtype == torch.int32 and dev[k].is_cuda and torch.equal(dev[k].cpu(), host[k]), k
