@@ -398,3 +398,104 @@ class Multi_DefectModel_new_GCN(nn.Module):
         all_feats = _ConcatColsFn.apply(cast_to(x, tail), h_feature, cast_to(t, tail))
         return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias,
                           None, torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ ablation heads
+class _MeanNodesFn(torch.autograd.Function):
+    """dgl.mean_nodes(g, "h") (GraphModel.py:299): per-graph mean of the node rows, [sum N, C] -> [B, C]."""
+
+    @staticmethod
+    def forward(ctx, h, off, B):
+        out = torch.empty((B, h.shape[1]), dtype=h.dtype, device=h.device)
+        call("segment_mean_fwd", ptr(h), ptr(off), ptr(out), B, h.shape[1], dt(h))
+        ctx.save_for_backward(off)
+        ctx.dims = (h.shape[0], B, h.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (off,) = ctx.saved_tensors
+        T, B, C = ctx.dims
+        dx = torch.empty((T, C), dtype=dout.dtype, device=dout.device)
+        call("segment_mean_bwd", ptr(dout.contiguous()), ptr(off), ptr(dx), B, C, dt(dx))
+        return dx, None, None
+
+
+class Multi_DefectModel(nn.Module):
+    """The pre-Rs_GCN head (reference GraphModel.py:214-303): GAT x2 -> Linear+ELU -> 8 hidden Linear+ELU -> dgl.mean_nodes ->
+    BatchNorm + Linear + ELU, concatenated with the image and text branches.  Same constructor, forward signature and state-dict
+    keys; the reference's dead h_func branch (:289,:296) is not computed."""
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_features, self.config, self.num_classes, self.act_dtype = 1024, config, config.MODEL.NUM_CLASSES, act_dtype
+        hfeat, embfeat, numheads = 512, 768, 4
+        self.p_gat = self.p_mlp = self.p_hidden = 0.1
+        self.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+        self.gat2 = GATConv(in_feats=hfeat * numheads, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+        self.fc = nn.Linear(hfeat * numheads, hfeat)
+        self.fconly = nn.Linear(embfeat, hfeat)
+        self.hidden = nn.ModuleList([nn.Linear(hfeat, hfeat) for _ in range(8)])
+        self.bn_text = nn.BatchNorm1d(embfeat)
+        self.fc_text = nn.Linear(embfeat, hfeat)
+        self.swinbn = nn.BatchNorm1d(self.num_features)
+        self.swinfc = nn.Linear(self.num_features, hfeat)
+        self.hbn = nn.BatchNorm1d(hfeat)
+        self.hfc = nn.Linear(hfeat, hfeat)
+        self.final_fc = nn.Linear(hfeat * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(hfeat * 3)
+        self.unused_parameter_prefixes = ("fconly.",)
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad, tr = self.act_dtype, self.training
+        ops.USE_SPLIT3[0] = False
+        h = g.ndata["_UNIX_NODE_EMB"]
+        hip.require_gpu(h, img_embedding, func_text_embedding)
+        cast = lambda v: ops.cast(v.contiguous(), ad) if v.dtype != ad else v
+        x = linear_act(batch_norm(cast(img_embedding), self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        t = linear_act(batch_norm(cast(func_text_embedding), self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        h = cast(h)
+        h = self.gat(g, h).view(h.shape[0], -1)
+        h = self.gat2(g, h).view(h.shape[0], -1)
+        h = linear_act(h, self.fc.weight, self.fc.bias, "elu", None, self.p_mlp, tr)
+        for hl in self.hidden:
+            h = linear_act(h, hl.weight, hl.bias, "elu", None, self.p_hidden, tr)
+        # per-graph tail in fp32 storage, like the main head's: train-mode BatchNorm over a handful of graphs divides by a tiny batch
+        # deviation and would amplify bf16 rounding of its inputs
+        hmean = cast_to(_MeanNodesFn.apply(h, g.index()["node_offsets"], g.batch_size), torch.float32)
+        hf = linear_act(batch_norm(hmean, self.hbn), self.hfc.weight, self.hfc.bias, "elu")
+        all_feats = _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32))
+        return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None, torch.float32)
+
+
+class Multi_DefectModel_noGraph(nn.Module):
+    """Image + text ablation (reference GraphModel.py:306-359): no graph branch at all.  The reference constructs fconly / hidden /
+    ln_text / hbn / hln / hfc and never uses them; they are kept for state-dict compatibility."""
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_features, self.config, self.num_classes, self.act_dtype = 1024, config, config.MODEL.NUM_CLASSES, act_dtype
+        hfeat, embfeat = 512, 768
+        self.fconly = nn.Linear(embfeat, hfeat)
+        self.hidden = nn.ModuleList([nn.Linear(hfeat, hfeat) for _ in range(8)])
+        self.bn_text = nn.BatchNorm1d(embfeat)
+        self.ln_text = nn.LayerNorm(embfeat)
+        self.fc_text = nn.Linear(embfeat, hfeat)
+        self.swinbn = nn.BatchNorm1d(self.num_features)
+        self.swinfc = nn.Linear(self.num_features, hfeat)
+        self.hbn = nn.BatchNorm1d(hfeat)
+        self.hln = nn.LayerNorm(hfeat)
+        self.hfc = nn.Linear(hfeat, hfeat)
+        self.final_fc = nn.Linear(hfeat * 2, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(hfeat * 2)
+        self.unused_parameter_prefixes = ("fconly.", "hidden.", "ln_text.", "hbn.", "hln.", "hfc.")
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad = self.act_dtype
+        ops.USE_SPLIT3[0] = False
+        hip.require_gpu(img_embedding, func_text_embedding)
+        cast = lambda v: ops.cast(v.contiguous(), ad) if v.dtype != ad else v
+        x = linear_act(batch_norm(cast(img_embedding), self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        t = linear_act(batch_norm(cast(func_text_embedding), self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        return linear_act(batch_norm(_ConcatColsFn.apply(x, t), self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None,
+                          torch.float32)

@@ -140,3 +140,32 @@ def head_param_shapes(num_classes=2, prefix=""):
     bn("hbn", hf); ln("hln", hf); lin("hfc", hf, hf)
     lin("final_fc", num_classes, hf * 3); bn("final_fc_bn", hf * 3)
     return {prefix + k: v for k, v in P.items()}
+
+
+# ------------------------------------------------------------------------------------------------ ablation heads
+def head_gat_mean_forward(sd, src, dst, batch_num_nodes, node_emb, img_embedding, func_text_embedding, training=False, prefix=""):
+    """Multi_DefectModel.forward (GraphModel.py:261-303, the pre-Rs_GCN head): GAT x2 -> MLP -> dgl.mean_nodes -> BN + Linear + ELU,
+    concatenated with the image and text branches.  (The h_func branch of :289,:296 feeds nothing and is not restated.)
+    Dropouts are identity (eval or rate 0)."""
+    P = prefix
+    x = F.elu(F.linear(_bn(sd, P + "swinbn.", img_embedding, training), sd[P + "swinfc.weight"], sd[P + "swinfc.bias"]))
+    t = F.elu(F.linear(_bn(sd, P + "bn_text.", func_text_embedding, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
+    h = gat_conv(sd, P + "gat.", node_emb, src, dst)
+    h = gat_conv(sd, P + "gat2.", h.reshape(h.shape[0], -1), src, dst)
+    h = F.elu(F.linear(h.reshape(h.shape[0], -1), sd[P + "fc.weight"], sd[P + "fc.bias"]))
+    for i in range(8):
+        h = F.elu(F.linear(h, sd[P + f"hidden.{i}.weight"], sd[P + f"hidden.{i}.bias"]))
+    off = [0] + torch.cumsum(torch.as_tensor(batch_num_nodes), 0).tolist()
+    hmean = torch.stack([h[off[b]:off[b + 1]].mean(0) for b in range(len(off) - 1)])            # dgl.mean_nodes
+    hf = F.elu(F.linear(_bn(sd, P + "hbn.", hmean, training), sd[P + "hfc.weight"], sd[P + "hfc.bias"]))
+    allf = torch.cat([x, hf, t], dim=1)
+    return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def head_nograph_forward(sd, img_embedding, func_text_embedding, training=False, prefix=""):
+    """Multi_DefectModel_noGraph.forward (GraphModel.py:345-359): image and text branches only."""
+    P = prefix
+    x = F.elu(F.linear(_bn(sd, P + "swinbn.", img_embedding, training), sd[P + "swinfc.weight"], sd[P + "swinfc.bias"]))
+    t = F.elu(F.linear(_bn(sd, P + "bn_text.", func_text_embedding, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
+    allf = torch.cat([x, t], dim=1)
+    return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])

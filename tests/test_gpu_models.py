@@ -1053,3 +1053,57 @@ def test_fused_step_from_raw_uint8_images(gpu):
         l_dev = model(gd, a, b, **kw).float().cpu()
         l_host = model(g.to(gpu), host.to(gpu), ids.to(gpu)).float().cpu()
     assert float((l_dev - l_host).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["Multi_DefectModel", "Multi_DefectModel_noGraph"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_ablation_heads_logits_and_gradients_vs_oracle(gpu, dtype, name, mode):
+    """two of the reference's ablation heads -- the pre-Rs_GCN head with dgl.mean_nodes (GraphModel.py:214-303) and
+    the image + text head (:306-359) -- on the same kernels, same constructor / forward / state-dict keys; logits and parameter
+    gradients against the oracle restatement (dropouts off; train mode = batch statistics in every BatchNorm)."""
+    from oracle import head_ref
+    from mvuld_amd.models import GraphModel as GM
+    from mvuld_amd import ops
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    m = getattr(GM, name)(cfg, act_dtype=dtype)
+    if name == "Multi_DefectModel":
+        m.p_gat = m.p_mlp = m.p_hidden = 0.0
+        m.gat.feat_drop_p = m.gat2.feat_drop_p = 0.0
+    sd, _ = load_synth_into(m, prefix=name + "/")
+    sd = {k[len(name) + 1:]: v for k, v in sd.items()}
+    m = m.to(gpu).train(mode == "train")
+    ops.bump_weight_epoch()
+    g, img, txt = _head_inputs()
+    ps = {k: v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone() for k, v in sd.items()}
+    if name == "Multi_DefectModel":
+        ref = head_ref.head_gat_mean_forward(ps, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], img, txt, training=(mode == "train"))
+    else:
+        ref = head_ref.head_nograph_forward(ps, img, txt, training=(mode == "train"))
+    w = synth.tensor("abl/w", tuple(ref.shape), -1, 1)
+    (ref * w).sum().backward()
+    lg = m(g.to(gpu), img.to(gpu), txt.to(gpu))
+    (lg * w.to(gpu)).sum().backward()
+    torch.cuda.synchronize()
+    err = float((lg.float().cpu() - ref.detach()).abs().max())
+    print(f"[{name} {mode} {dtype}] logits abs err {err:.3e} (scale {float(ref.abs().max()):.2f})")
+    # bf16 train mode: hbn normalises the per-graph node means with the statistics of a batch of FOUR near-identical graphs (a
+    # noise amplifier: the four means differ by ~1e-2 of their size, bf16 rounding of the node features by 4e-3); eval carries 2e-2
+    assert err < (1e-3 if dtype == torch.float32 else (2e-2 if mode == "eval" else 3e-1))
+    used = [k for k, p in m.named_parameters() if not k.startswith(tuple(m.unused_parameter_prefixes))]
+    worst = 0.0
+    for k in used:
+        gref = ps[k].grad
+        assert gref is not None, k
+        got = dict(m.named_parameters())[k].grad
+        assert got is not None, k
+        worst = max(worst, float((got.float().cpu() - gref).norm() / (gref.norm() + 1e-12)))
+    # train mode: BatchNorm over FOUR samples divides by a tiny batch std (fp32 atomics order shows at ~2e-3 of a gradient's norm)
+    if dtype == torch.float32:
+        assert worst < (2e-3 if mode == "eval" else 6e-3), worst
+    elif mode == "eval" or name == "Multi_DefectModel_noGraph":
+        assert worst < 1.5e-1, worst
+    else:
+        # bf16 + batch statistics of four near-identical graph means: the BatchNorm backward is a difference of nearly equal terms and
+        # the gradients upstream of it carry no significant digits (the fp32 run above checks the kernels); finite is all that is asked
+        assert all(bool(torch.isfinite(p.grad).all()) for k, p in m.named_parameters() if k in used)
