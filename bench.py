@@ -109,6 +109,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         init_distributed(local)
+    elif os.environ.get("MVULD_FORCE_ALLREDUCE") == "1":
+        # rehearsal of the data-parallel control flow on ONE GPU: a single-rank RCCL group, every per-stage all-reduce launched from
+        # inside backward (with the stream joins in front of it), finish() -- everything but the wire time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0)
     assert world_size() == max(1, world)
     from mvuld_amd.models.GraphModel import cross_entropy
 
@@ -299,6 +305,7 @@ def main():
         print(json.dumps(out))
     if world_size() > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
