@@ -75,6 +75,9 @@ int mvuld_fp8_roll_scales(float* state, int n, mvuld_stream_t stream);
 /* Routing of mvuld_gemm_nt's bf16 -> bf16 plain-store products to the persistent 256 x 256-tile kernel (csrc/gemm_p256.hip):
  * 0 = never, 1 = default rule (>= 160 tiles, N % 128 == 0: the tall Linear layers of the two encoders, same call sites as
  * mvuld_gemm_nt), 2 = every legal shape (K % 32 == 0, K >= 128, N % 8 == 0, no ELU epilogues; tests and A/B timing).  Host-side setting, no stream. */
+/* CUs the 256x256 weight-gradient kernel plans its contraction splits for: 0 = all (best alone); the fused training step sets half
+ * the chip while its streams run concurrently (a smaller footprint beside the data-gradient chain: step -1 %) */
+int mvuld_set_gemm_tn256_budget(int cus);
 int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
  * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */

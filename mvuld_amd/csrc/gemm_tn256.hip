@@ -18,6 +18,7 @@
 // descriptors sized to the M valid rows, so the rows of the last 32-token slab beyond M read as zeros (out-of-range buffer loads
 // return 0) and add nothing -- the pad-free text encoder hands over token counts that are multiples of nothing.
 #include "gemm_common.h"
+#include <atomic>
 
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
 
@@ -181,19 +182,29 @@ __global__ __launch_bounds__(256) void gemm_tn256_reduce_k(const float* __restri
     }
 }
 
-static int tn256_num_cus() {
+static int tn256_all_cus() {
     static const int n = [] {
         int dev = 0, v = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        // The splits are planned for HALF the chip: in the training step this kernel always runs beside the data-gradient chain of
-        // another stream (one LDS-heavy workgroup per CU either way), and a 128-workgroup footprint with half the slab traffic
-        // is worth 1 % of the step over a 256-workgroup one that is ~10 % faster alone.  MVULD_TN256_CUS overrides (isolated timing).
-        v = v > 1 ? v / 2 : 1;
-        const char* e = getenv("MVULD_TN256_CUS");
-        if (e && atoi(e) > 0) v = atoi(e);
-        return v;
+        return v > 0 ? v : 256;
     }();
     return n;
+}
+// CUs the contraction splits are planned for.  Alone on the chip: all of them.  In the multi-stream training step this kernel always
+// runs beside the data-gradient chain of another stream (one LDS-heavy workgroup per CU either way); there a footprint of HALF the
+// chip, with half the slab traffic, is ~1.8x slower for the kernel and 1 % faster for the step (the host tells which case it is:
+// mvuld_set_gemm_tn256_budget).  MVULD_TN256_CUS pins the number (tuning runs).
+static std::atomic<int> g_tn256_budget{0};
+extern "C" int mvuld_set_gemm_tn256_budget(int cus) {
+    MV_CHECK_ARG(cus >= 0, "set_gemm_tn256_budget: cus >= 0 (0 = every CU)");
+    g_tn256_budget.store(cus, std::memory_order_relaxed);
+    return 0;
+}
+static int tn256_num_cus() {
+    static const int pinned = [] { const char* e = getenv("MVULD_TN256_CUS"); return e ? atoi(e) : 0; }();
+    if (pinned > 0) return pinned;
+    const int b = g_tn256_budget.load(std::memory_order_relaxed);
+    return b > 0 && b < tn256_all_cus() ? b : tn256_all_cus();
 }
 
 // split plan of the 256 x 256-tile kernel: 0 splits = shape not eligible

@@ -28,6 +28,7 @@ class FusedMVulD(nn.Module):
         self.head = Multi_DefectModel_new_GCN(config, act_dtype=act_dtype)
         self._side = None
         self._gs = None
+        self._tn_budget = -1
         self._wg = None
         self._inflight = []
         self.max_steps_in_flight = 2          # 0 = do not throttle the host (bench.py's enqueue-cost measurement)
@@ -67,6 +68,11 @@ class FusedMVulD(nn.Module):
         reference caches them offline: data_list.py:265-317) instead of being read from g.ndata."""
         from .. import hip, ops
         concurrent = images.is_cuda and os.environ.get("MVULD_CONCURRENT", "1") != "0" and not hip.TIMING.enabled
+        if images.is_cuda and self.training:
+            # weight-gradient kernels beside the chain: planned for half the chip (gemm_tn256.hip); alone (one stream): all of it
+            if self._tn_budget < 0:
+                self._tn_budget = torch.cuda.get_device_properties(images.device).multi_processor_count // 2
+            hip.LIB.fn("mvuld_set_gemm_tn256_budget")(self._tn_budget if concurrent else 0)
         if os.environ.get("MVULD_PACK_TEXT", "1") == "0":
             seq_lens = None
         self.unixcoder.return_tokens = False                           # only the sentence vector is read here
