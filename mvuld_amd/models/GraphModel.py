@@ -499,3 +499,142 @@ class Multi_DefectModel_noGraph(nn.Module):
         t = linear_act(batch_norm(cast(func_text_embedding), self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
         return linear_act(batch_norm(_ConcatColsFn.apply(x, t), self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None,
                           torch.float32)
+
+
+class _EluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        call("elu_fwd", ptr(x), ptr(y), x.numel(), dt(x))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), y, 1)
+
+
+class _RQ3Head(nn.Module):
+    """The reference's RQ3 ablation family (GraphModel.py:362-949), one class per (pos, gat, gcn) switch triple, all on the kernels of
+    the full head (= 111, Multi_DefectModel_new_GCN):
+      node features   gat: GATConv x2 -> fc + ELU -> 8 hidden Linear + ELU;  else: fconly + ELU
+      read-out        neither pos nor gcn: dgl.mean_nodes -> hbn -> hfc -> ELU                                  (000)
+                      pos, no gcn: pad to 100 nodes, bn_gat / fc_gat(512->480) / ELU and bn_bbox / fc_bbox(4->32) / ELU, concat,
+                                   mean over the 100 slots                                                      (100, 110)
+                      gcn, no pos: pad to 100 nodes, bn_gat (-> fc_gat 512->512 when there is no GAT) -> ELU, 8 x Rs_GCN,
+                                   l2norm over nodes, mean                                                      (001, 011)
+    Each subclass constructs exactly the parameters its reference class constructs (state-dict parity), used or not."""
+    POS = GAT = GCN = False
+    P_DROP = 0.2
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_features, self.config, self.num_classes, self.act_dtype = 1024, config, config.MODEL.NUM_CLASSES, act_dtype
+        hfeat, embfeat, numheads = 512, 768, 4
+        self.p_gat = self.p_mlp = self.p_hidden = self.P_DROP
+        self.chain_fp32 = os.environ.get("MVULD_CHAIN_FP32", "1") == "1"
+        unused = ["hidden."] if not self.GAT else ["fconly."]
+        if self.GAT:
+            self.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+            self.gat2 = GATConv(in_feats=hfeat * numheads, out_feats=hfeat, num_heads=numheads, feat_drop=self.p_gat)
+            self.fc = nn.Linear(hfeat * numheads, hfeat)
+        self.fconly = nn.Linear(embfeat, hfeat)
+        self.hidden = nn.ModuleList([nn.Linear(hfeat, hfeat) for _ in range(8)])
+        if self.GCN:
+            for i in range(1, 9):
+                setattr(self, f"Rs_GCN_{i}", Rs_GCN(in_channels=512, inter_channels=512))
+        self.bn_text = nn.BatchNorm1d(embfeat)
+        if not (self.POS and self.GAT):                      # 110 has no ln_text / hbn / hln / hfc
+            self.ln_text = nn.LayerNorm(embfeat)
+            unused.append("ln_text.")
+        self.fc_text = nn.Linear(embfeat, hfeat)
+        self.max_node = 100
+        if self.POS or self.GCN:
+            self.bn_gat = nn.BatchNorm1d(self.max_node)
+            self.fc_gat = nn.Linear(512, 480 if self.POS else 512)
+            if self.GCN and self.GAT:
+                unused.append("fc_gat.")                     # 011 applies bn_gat + ELU only (:902)
+        if self.POS:
+            self.bn_bbox = nn.BatchNorm1d(self.max_node)
+            self.fc_bbox = nn.Linear(4, 32)
+        self.swinbn = nn.BatchNorm1d(self.num_features)
+        self.swinfc = nn.Linear(self.num_features, hfeat)
+        if not (self.POS and self.GAT):
+            self.hbn = nn.BatchNorm1d(hfeat)
+            self.hln = nn.LayerNorm(hfeat)
+            self.hfc = nn.Linear(hfeat, hfeat)
+            unused.append("hln.")
+            if self.POS or self.GCN:
+                unused += ["hbn.", "hfc."]
+        self.final_fc = nn.Linear(hfeat * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(hfeat * 3)
+        self.unused_parameter_prefixes = tuple(unused)
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad, tr, B = self.act_dtype, self.training, g.batch_size
+        ops.USE_SPLIT3[0] = self.GCN and ad == torch.bfloat16
+        h = g.ndata["_UNIX_NODE_EMB"]
+        hip.require_gpu(h, img_embedding, func_text_embedding)
+        cast = lambda v: ops.cast(v.contiguous(), ad) if v.dtype != ad else v
+        x = linear_act(batch_norm(cast(img_embedding), self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        t = linear_act(batch_norm(cast(func_text_embedding), self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        h = cast(h)
+        if self.GAT:
+            h = self.gat(g, h).view(h.shape[0], -1)
+            h = self.gat2(g, h).view(h.shape[0], -1)
+            h = linear_act(h, self.fc.weight, self.fc.bias, "elu", None, self.p_mlp, tr)
+            for hl in self.hidden:
+                h = linear_act(h, hl.weight, hl.bias, "elu", None, self.p_hidden, tr)
+        else:
+            h = linear_act(h, self.fconly.weight, self.fconly.bias, "elu", None, self.p_mlp, tr)
+        off = g.index()["node_offsets"]
+        if not (self.POS or self.GCN):
+            hmean = cast_to(_MeanNodesFn.apply(h, off, B), torch.float32)
+            hf = linear_act(batch_norm(hmean, self.hbn), self.hfc.weight, self.hfc.bias, "elu")
+        else:
+            g.ndata['HGATOUTPUT'] = h
+            g.ndata['HFGATOUTPUT'] = g.ndata["pos_emb"]
+            h_i = batch_norm(_SegmentPadFn.apply(h, off, B, self.max_node), self.bn_gat)                  # [B,100,512]
+            if self.GCN and self.GAT:
+                h_i = _EluFn.apply(h_i)
+            else:
+                h_i = linear_act(h_i, self.fc_gat.weight, self.fc_gat.bias, "elu")
+            if self.POS:
+                pos_i = _SegmentPadFn.apply(cast(g.ndata["pos_emb"]), off, B, self.max_node)
+                pos_i = linear_act(batch_norm(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")
+                v = _ConcatColsFn.apply(h_i, pos_i).view(B * self.max_node, 512)
+                slots = (torch.arange(B + 1, dtype=torch.int32) * self.max_node).to(v.device)
+                hf = cast_to(_MeanNodesFn.apply(v, slots, B), torch.float32)                               # torch.mean(dim=1)
+            else:
+                v = cast_to(h_i.reshape(B * self.max_node, 512), torch.float32 if self.chain_fp32 else ad)
+                for i in range(1, 9):
+                    v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
+                hf = _L2NormMeanFn.apply(cast_to(v, torch.float32), B)
+        all_feats = _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32))
+        return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None, torch.float32)
+
+
+class Multi_DefectModel_000(_RQ3Head):
+    """MLP + mean_nodes (reference GraphModel.py:362-430)."""
+
+
+class Multi_DefectModel_001(_RQ3Head):
+    """GCN only (:433-531)."""
+    GCN = True
+
+
+class Multi_DefectModel_100(_RQ3Head):
+    """Positional features only (:534-615)."""
+    POS = True
+
+
+class Multi_DefectModel_110(_RQ3Head):
+    """Positional features + GAT (:618-718)."""
+    POS = GAT = True
+    P_DROP = 0.1
+
+
+class Multi_DefectModel_011(_RQ3Head):
+    """GAT + GCN (:830-947)."""
+    GAT = GCN = True

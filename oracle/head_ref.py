@@ -169,3 +169,40 @@ def head_nograph_forward(sd, img_embedding, func_text_embedding, training=False,
     t = F.elu(F.linear(_bn(sd, P + "bn_text.", func_text_embedding, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
     allf = torch.cat([x, t], dim=1)
     return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def head_rq3_forward(sd, pos, gat, gcn, src, dst, batch_num_nodes, node_emb, pos_emb, img_embedding, func_text_embedding, training=False,
+                     prefix=""):
+    """The RQ3 ablation heads Multi_DefectModel_{000,001,100,110,011}.forward (GraphModel.py:401-430, 486-531, 577-615, 669-718,
+    894-947) as one function of the (pos, gat, gcn) switches.  Dropouts are identity."""
+    P = prefix
+    x = F.elu(F.linear(_bn(sd, P + "swinbn.", img_embedding, training), sd[P + "swinfc.weight"], sd[P + "swinfc.bias"]))
+    t = F.elu(F.linear(_bn(sd, P + "bn_text.", func_text_embedding, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
+    if gat:
+        h = gat_conv(sd, P + "gat.", node_emb, src, dst)
+        h = gat_conv(sd, P + "gat2.", h.reshape(h.shape[0], -1), src, dst)
+        h = F.elu(F.linear(h.reshape(h.shape[0], -1), sd[P + "fc.weight"], sd[P + "fc.bias"]))
+        for i in range(8):
+            h = F.elu(F.linear(h, sd[P + f"hidden.{i}.weight"], sd[P + f"hidden.{i}.bias"]))
+    else:
+        h = F.elu(F.linear(node_emb, sd[P + "fconly.weight"], sd[P + "fconly.bias"]))
+    if not (pos or gcn):
+        off = [0] + torch.cumsum(torch.as_tensor(batch_num_nodes), 0).tolist()
+        hmean = torch.stack([h[off[b]:off[b + 1]].mean(0) for b in range(len(off) - 1)])
+        hf = F.elu(F.linear(_bn(sd, P + "hbn.", hmean, training), sd[P + "hfc.weight"], sd[P + "hfc.bias"]))
+    else:
+        h_i = _bn(sd, P + "bn_gat.", unbatch_pad(h, batch_num_nodes), training)
+        h_i = F.elu(h_i) if (gcn and gat) else F.elu(F.linear(h_i, sd[P + "fc_gat.weight"], sd[P + "fc_gat.bias"]))
+        if pos:
+            pos_i = unbatch_pad(pos_emb, batch_num_nodes)
+            pos_i = F.elu(F.linear(_bn(sd, P + "bn_bbox.", pos_i, training), sd[P + "fc_bbox.weight"], sd[P + "fc_bbox.bias"]))
+            hf = torch.cat([h_i, pos_i], dim=2).mean(dim=1)
+        else:
+            gg = h_i.permute(0, 2, 1)
+            for i in range(1, 9):
+                gg, _ = rs_gcn(sd, P + f"Rs_GCN_{i}.", gg, training)
+            gg = gg.permute(0, 2, 1)
+            gg = gg / gg.pow(2).sum(dim=1, keepdim=True).sqrt()
+            hf = gg.mean(dim=1)
+    allf = torch.cat([x, hf, t], dim=1)
+    return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])

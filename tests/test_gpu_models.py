@@ -1107,3 +1107,47 @@ def test_ablation_heads_logits_and_gradients_vs_oracle(gpu, dtype, name, mode):
         # bf16 + batch statistics of four near-identical graph means: the BatchNorm backward is a difference of nearly equal terms and
         # the gradients upstream of it carry no significant digits (the fp32 run above checks the kernels); finite is all that is asked
         assert all(bool(torch.isfinite(p.grad).all()) for k, p in m.named_parameters() if k in used)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,flags", [("Multi_DefectModel_000", (0, 0, 0)), ("Multi_DefectModel_001", (0, 0, 1)), ("Multi_DefectModel_100", (1, 0, 0)),
+                                        ("Multi_DefectModel_110", (1, 1, 0)), ("Multi_DefectModel_011", (0, 1, 1))])
+def test_rq3_ablation_heads_vs_oracle(gpu, dtype, name, flags):
+    """the reference's RQ3 ablation family (pos / gat / gcn switches, GraphModel.py:362-949) on the kernels of the
+    full head; eval logits and (fp32) parameter gradients against the oracle restatement, state-dict keys = the reference class's."""
+    from oracle import head_ref
+    from mvuld_amd.models import GraphModel as GM
+    from mvuld_amd import ops
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    m = getattr(GM, name)(cfg, act_dtype=dtype)
+    m.p_gat = m.p_mlp = m.p_hidden = 0.0
+    if flags[1]:
+        m.gat.feat_drop_p = m.gat2.feat_drop_p = 0.0
+    sd, _ = load_synth_into(m, prefix=name + "/")
+    sd = {k[len(name) + 1:]: v for k, v in sd.items()}
+    for k in list(sd):                                   # keep the 8-block residual chain well conditioned (as the main head's goldens)
+        if k.startswith("Rs_GCN_") and k.endswith("W.1.weight"):
+            sd[k] = 0.05 + 0.1 * synth.tensor("rq3/" + k, tuple(sd[k].shape), 0.0, 1.0)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(gpu).eval()
+    ops.bump_weight_epoch()
+    g, img, txt = _head_inputs()
+    ps = {k: v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone() for k, v in sd.items()}
+    ref = head_ref.head_rq3_forward(ps, *map(bool, flags), g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"],
+                                    img, txt, training=False)
+    w = synth.tensor("rq3/w", tuple(ref.shape), -1, 1)
+    (ref * w).sum().backward()
+    lg = m(g.to(gpu), img.to(gpu), txt.to(gpu))
+    (lg * w.to(gpu)).sum().backward()
+    torch.cuda.synchronize()
+    err = float((lg.float().cpu() - ref.detach()).abs().max())
+    print(f"[{name} eval {dtype}] logits abs err {err:.3e} (scale {float(ref.abs().max()):.2f})")
+    assert err < (1e-3 if dtype == torch.float32 else 2e-2)
+    if dtype == torch.float32:
+        worst = 0.0
+        for k, p in m.named_parameters():
+            if k.startswith(tuple(m.unused_parameter_prefixes)):
+                continue
+            assert ps[k].grad is not None and p.grad is not None, k
+            worst = max(worst, float((p.grad.float().cpu() - ps[k].grad).norm() / (ps[k].grad.norm() + 1e-12)))
+        assert worst < 3e-3, worst
