@@ -638,3 +638,54 @@ class Multi_DefectModel_110(_RQ3Head):
 class Multi_DefectModel_011(_RQ3Head):
     """GAT + GCN (:830-947)."""
     GAT = GCN = True
+
+
+class Multi_DefectModel_NOGAT(nn.Module):
+    """Node embeddings straight into the Rs_GCN chain, no GAT / MLP (reference GraphModel.py:950-1050): pad to 100 nodes,
+    bn_gat -> fc_gat(768 -> 480) -> ELU and bn_bbox -> fc_bbox(4 -> 32) -> ELU, concat, 8 x Rs_GCN, l2norm over nodes, mean."""
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        self.num_features, self.config, self.num_classes, self.act_dtype = 1024, config, config.MODEL.NUM_CLASSES, act_dtype
+        hfeat, embfeat = 512, 768
+        self.chain_fp32 = os.environ.get("MVULD_CHAIN_FP32", "1") == "1"
+        for i in range(1, 9):
+            setattr(self, f"Rs_GCN_{i}", Rs_GCN(in_channels=512, inter_channels=512))
+        self.bn_text = nn.BatchNorm1d(embfeat)
+        self.ln_text = nn.LayerNorm(embfeat)
+        self.fc_text = nn.Linear(embfeat, hfeat)
+        self.max_node = 100
+        self.bn_gat = nn.BatchNorm1d(self.max_node)
+        self.fc_gat = nn.Linear(768, 480)
+        self.bn_bbox = nn.BatchNorm1d(self.max_node)
+        self.fc_bbox = nn.Linear(4, 32)
+        self.swinbn = nn.BatchNorm1d(self.num_features)
+        self.swinfc = nn.Linear(self.num_features, hfeat)
+        self.hbn = nn.BatchNorm1d(hfeat)
+        self.hln = nn.LayerNorm(hfeat)
+        self.hfc = nn.Linear(hfeat, hfeat)
+        self.final_fc = nn.Linear(hfeat * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(hfeat * 3)
+        self.unused_parameter_prefixes = ("ln_text.", "hbn.", "hln.", "hfc.")
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad, B = self.act_dtype, g.batch_size
+        ops.USE_SPLIT3[0] = ad == torch.bfloat16
+        h = g.ndata["_UNIX_NODE_EMB"]
+        hip.require_gpu(h, img_embedding, func_text_embedding)
+        cast = lambda v: ops.cast(v.contiguous(), ad) if v.dtype != ad else v
+        x = linear_act(batch_norm(cast(img_embedding), self.swinbn), self.swinfc.weight, self.swinfc.bias, "elu")
+        t = linear_act(batch_norm(cast(func_text_embedding), self.bn_text), self.fc_text.weight, self.fc_text.bias, "elu")
+        g.ndata['HGATOUTPUT'] = h
+        g.ndata['HFGATOUTPUT'] = g.ndata["pos_emb"]
+        off = g.index()["node_offsets"]
+        h_i = _SegmentPadFn.apply(cast(h), off, B, self.max_node)                                         # [B,100,768]
+        pos_i = _SegmentPadFn.apply(cast(g.ndata["pos_emb"]), off, B, self.max_node)                      # [B,100,4]
+        h_i = linear_act(batch_norm(h_i, self.bn_gat), self.fc_gat.weight, self.fc_gat.bias, "elu")       # [B,100,480]
+        pos_i = linear_act(batch_norm(pos_i, self.bn_bbox), self.fc_bbox.weight, self.fc_bbox.bias, "elu")
+        v = cast_to(_ConcatColsFn.apply(h_i, pos_i).view(B * self.max_node, 512), torch.float32 if self.chain_fp32 else ad)
+        for i in range(1, 9):
+            v, _ = getattr(self, f"Rs_GCN_{i}").forward_rows(v, B)
+        hf = _L2NormMeanFn.apply(cast_to(v, torch.float32), B)
+        all_feats = _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32))
+        return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None, torch.float32)

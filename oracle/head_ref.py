@@ -206,3 +206,21 @@ def head_rq3_forward(sd, pos, gat, gcn, src, dst, batch_num_nodes, node_emb, pos
             hf = gg.mean(dim=1)
     allf = torch.cat([x, hf, t], dim=1)
     return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def head_nogat_forward(sd, batch_num_nodes, node_emb, pos_emb, img_embedding, func_text_embedding, training=False, prefix=""):
+    """Multi_DefectModel_NOGAT.forward (GraphModel.py:1003-1050): raw node embeddings + positions -> Rs_GCN x8 -> l2norm -> mean."""
+    P = prefix
+    x = F.elu(F.linear(_bn(sd, P + "swinbn.", img_embedding, training), sd[P + "swinfc.weight"], sd[P + "swinfc.bias"]))
+    t = F.elu(F.linear(_bn(sd, P + "bn_text.", func_text_embedding, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
+    h_i = unbatch_pad(node_emb, batch_num_nodes)
+    pos_i = unbatch_pad(pos_emb, batch_num_nodes)
+    h_i = F.elu(F.linear(_bn(sd, P + "bn_gat.", h_i, training), sd[P + "fc_gat.weight"], sd[P + "fc_gat.bias"]))
+    pos_i = F.elu(F.linear(_bn(sd, P + "bn_bbox.", pos_i, training), sd[P + "fc_bbox.weight"], sd[P + "fc_bbox.bias"]))
+    gg = torch.cat([h_i, pos_i], dim=2).permute(0, 2, 1)
+    for i in range(1, 9):
+        gg, _ = rs_gcn(sd, P + f"Rs_GCN_{i}.", gg, training)
+    gg = gg.permute(0, 2, 1)
+    gg = gg / gg.pow(2).sum(dim=1, keepdim=True).sqrt()
+    allf = torch.cat([x, gg.mean(dim=1), t], dim=1)
+    return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])

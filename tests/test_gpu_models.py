@@ -1110,7 +1110,7 @@ def test_ablation_heads_logits_and_gradients_vs_oracle(gpu, dtype, name, mode):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("name,flags", [("Multi_DefectModel_000", (0, 0, 0)), ("Multi_DefectModel_001", (0, 0, 1)), ("Multi_DefectModel_100", (1, 0, 0)),
+@pytest.mark.parametrize("name,flags", [("Multi_DefectModel_NOGAT", None), ("Multi_DefectModel_000", (0, 0, 0)), ("Multi_DefectModel_001", (0, 0, 1)), ("Multi_DefectModel_100", (1, 0, 0)),
                                         ("Multi_DefectModel_110", (1, 1, 0)), ("Multi_DefectModel_011", (0, 1, 1))])
 def test_rq3_ablation_heads_vs_oracle(gpu, dtype, name, flags):
     """the reference's RQ3 ablation family (pos / gat / gcn switches, GraphModel.py:362-949) on the kernels of the
@@ -1120,9 +1120,10 @@ def test_rq3_ablation_heads_vs_oracle(gpu, dtype, name, flags):
     from mvuld_amd import ops
     cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
     m = getattr(GM, name)(cfg, act_dtype=dtype)
-    m.p_gat = m.p_mlp = m.p_hidden = 0.0
-    if flags[1]:
-        m.gat.feat_drop_p = m.gat2.feat_drop_p = 0.0
+    if flags is not None:
+        m.p_gat = m.p_mlp = m.p_hidden = 0.0
+        if flags[1]:
+            m.gat.feat_drop_p = m.gat2.feat_drop_p = 0.0
     sd, _ = load_synth_into(m, prefix=name + "/")
     sd = {k[len(name) + 1:]: v for k, v in sd.items()}
     for k in list(sd):                                   # keep the 8-block residual chain well conditioned (as the main head's goldens)
@@ -1133,8 +1134,11 @@ def test_rq3_ablation_heads_vs_oracle(gpu, dtype, name, flags):
     ops.bump_weight_epoch()
     g, img, txt = _head_inputs()
     ps = {k: v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone() for k, v in sd.items()}
-    ref = head_ref.head_rq3_forward(ps, *map(bool, flags), g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"],
-                                    img, txt, training=False)
+    if flags is None:
+        ref = head_ref.head_nogat_forward(ps, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt, training=False)
+    else:
+        ref = head_ref.head_rq3_forward(ps, *map(bool, flags), g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"],
+                                        img, txt, training=False)
     w = synth.tensor("rq3/w", tuple(ref.shape), -1, 1)
     (ref * w).sum().backward()
     lg = m(g.to(gpu), img.to(gpu), txt.to(gpu))
