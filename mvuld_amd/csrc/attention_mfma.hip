@@ -73,6 +73,12 @@ __device__ __forceinline__ int64_t am_token(const AttnGeom& g, int b, int w, int
     return ((int64_t)b * g.res + oy) * g.res + ox;
 }
 __device__ __forceinline__ int am_rid(const AttnGeom& g, int s) { return s < g.res - g.ws ? 0 : (s < g.res - g.shift ? 1 : 2); }
+// A shifted window mixes mask regions only in the last row / column of windows (where the rolled image wraps); every other window
+// is one region (id 0) and takes the unmasked loops: 9 of the 16 windows of stage 0, 1 of the 4 of stage 1.
+__device__ __forceinline__ bool am_window_masked(const AttnGeom& g, int w) {
+    const int nwx = g.res / g.ws;
+    return g.shift > 0 && ((w / nwx) == nwx - 1 || (w % nwx) == nwx - 1);
+}
 // per-token info word.  MODE 0: (iy*(2ws-1)+ix) | region << 16 ; MODE 1: validity in bit 0.  Bit 30 marks a padding row
 // (all other fields then hold safe in-range values, so the hot loops stay branch-free).
 #define AM_PAD (1 << 30)
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;          // keys covered by pad-free 64-key blocks
     const bool g4 = MODE == 0 && (g.ws & 3) == 0; // four consecutive window positions share a row: adjacent bias-table words
+    const bool wmask = MASK && am_window_masked(g, w);
     bf16x8_t ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -383,12 +390,17 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
                 am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
             for (; kb < Np; kb += 32)
                 am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
-        } else if (g4) {
-            for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
-            for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
         } else {
-            for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MASK, false, 4, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
-            for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MASK, true, 2, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);
+#define AM_FWD_SWEEP(MK)                                                                                                                       \
+            if (g4) {                                                                                                                          \
+                for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MK, false, 4, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones); \
+                for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MK, true, 2, true>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);      \
+            } else {                                                                                                                           \
+                for (; kb < nfull64; kb += 64) am_fwd_block<HD, MODE, MK, false, 4, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones); \
+                for (; kb < Np; kb += 32) am_fwd_block<HD, MODE, MK, true, 2, false>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones);     \
+            }
+            if (MASK && wmask) { AM_FWD_SWEEP(true) } else { AM_FWD_SWEEP(false) }
+#undef AM_FWD_SWEEP
         }
         const float l = lacc[0];             // every row of ones . P^T is the same sum over ALL keys: no cross-lane reduce
         if (qok) {
@@ -534,6 +546,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
     const bool g4 = MODE == 0 && (g.ws & 3) == 0;
+    const bool wmask = MASK && am_window_masked(g, w);
     // MODE 0 (hd = 32 windows): two query tiles per wave and 32-key blocks; the text encoder keeps one tile and 64-key blocks
     // (its K/V image at hd = 64 leaves no registers for a second tile's accumulators)
     constexpr int QT = (MODE == 0 && HD == 32) ? 2 : 1;
@@ -591,24 +604,32 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         }
         int kb = 0;
         if (QT == 2) {
-            if (g4) {
-                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MASK, false, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
-                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
-            } else {
-                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MASK, false, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
-                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+#define AM_DQ2_SWEEP(MK)                                                                                                                       \
+            if (g4) {                                                                                                                          \
+                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MK, false, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);      \
+            } else {                                                                                                                           \
+                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MK, false, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);     \
             }
+            if (MASK && wmask) { AM_DQ2_SWEEP(true) } else { AM_DQ2_SWEEP(false) }
+#undef AM_DQ2_SWEEP
         } else if (MODE == 1 && drop) {
             for (; kb < nfull64; kb += 64)
                 am_dq_block<HD, MODE, MASK, false, 4, false, MODE == 1, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
             for (; kb < Np; kb += 32)
                 am_dq_block<HD, MODE, MASK, true, 2, false, MODE == 1, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb, dseed, g.drop_thr, g.drop_inv);
-        } else if (g4) {
-            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
-            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
         } else {
-            for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MASK, false, 4, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
-            for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MASK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);
+#define AM_DQ_SWEEP(MK)                                                                                                                        \
+            if (g4) {                                                                                                                          \
+                for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MK, false, 4, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);      \
+            } else {                                                                                                                           \
+                for (; kb < nfull64; kb += 64) am_dq_block<HD, MODE, MK, false, 4, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
+                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);     \
+            }
+            if (MASK && wmask) { AM_DQ_SWEEP(true) } else { AM_DQ_SWEEP(false) }
+#undef AM_DQ_SWEEP
         }
         // dq[q][d][r] = d(q~)[query fc][dim d*16 + 4*fg + r]   (q~ = tau * q^ in natural units)
 #pragma unroll
@@ -983,6 +1004,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     __syncthreads();
 
     const bool g4 = MODE == 0 && (g.ws & 3) == 0;
+    const bool wmask = MASK && am_window_masked(g, w);
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
     for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * (blockDim.x >> 6)) {
@@ -1022,12 +1044,17 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
                 am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
             for (; qb < Np; qb += 32)
                 am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
-        } else if (g4) {
-            for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
-            for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
         } else {
-            for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MASK, false, 4, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
-            for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MASK, true, 2, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);
+#define AM_DKV_SWEEP(MK)                                                                                                                       \
+            if (g4) {                                                                                                                          \
+                for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); \
+                for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);      \
+            } else {                                                                                                                           \
+                for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MK, false, 4, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); \
+                for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MK, true, 2, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);     \
+            }
+            if (MASK && wmask) { AM_DKV_SWEEP(true) } else { AM_DKV_SWEEP(false) }
+#undef AM_DKV_SWEEP
         }
         // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc; dk was accumulated against q~ * log2(e)
         if (kok) {
