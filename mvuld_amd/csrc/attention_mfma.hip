@@ -417,24 +417,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-// one lane per 16-byte chunk (consecutive lanes read consecutive memory), hd/8 lanes fold one (token, head)
-__global__ __launch_bounds__(256) void attn_delta_k(const bf16* __restrict__ out, const bf16* __restrict__ dout, float* __restrict__ delta,
-                                                    int64_t ntok, int H, int hd) {
-    const int cpr = hd >> 3;                                                  // chunks per (token, head): 4 or 8
-    const int64_t nchunk = ntok * H * cpr;
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t cc = c < nchunk ? c : nchunk - 1;
-    U8 a, d;
-    a.u = *(const uint4*)(out + cc * 8);
-    d.u = *(const uint4*)(dout + cc * 8);
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += (float)a.e[k] * (float)d.e[k];
-    for (int o = 1; o < cpr; o <<= 1) s += __shfl_xor(s, o, 64);
-    if (c < nchunk && (c % cpr) == 0) delta[c / cpr] = s;
-}
-
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ d logit_scale)
 // one block of NT key tiles: dS^T = P^T o (dP^T - delta), dQ^T += K^T . dS^T   (scores in log2 units, gradients in natural units)
 // QT query tiles per wave share every LDS read of the block -- the K and V fragments of the two score products and the transposed
@@ -504,8 +486,9 @@ template <int HD, int MODE, bool MASK>
 __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd_dq_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                           const float* __restrict__ logit_scale, const int* __restrict__ valid,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                          float* __restrict__ dlogit_scale, bf16* __restrict__ qt_out, int Npad, int qsplit) {
+                                                          float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                          float* __restrict__ dlogit_scale, bf16* __restrict__ qt_out, int Npad, int qsplit,
+                                                          const bf16* __restrict__ outp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KLD = AmTile<HD, HD == 32>::LD;
     bf16* Ks = (bf16*)smem;                       // [Npad][KLD]
@@ -575,16 +558,21 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
             regq[q] = (qinf >> 16) & 0xff;
             vq[q] = qinf;
             float f[HD / 32][8];
-            float ss = 0.f;
+            float ss = 0.f, dsum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
-                U8 x, y;
+                U8 x, y, o;
                 x.u = *(const uint4*)(qkv + tq[q] * rs + h * HD + ks * 32 + fg * 8);
                 y.u = qok[q] ? *(const uint4*)(dout + tq[q] * C + h * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
+                o.u = *(const uint4*)(outp + tq[q] * C + h * HD + ks * 32 + fg * 8);
                 dof[q][ks] = y.v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; }
+                for (int e = 0; e < 8; ++e) { f[ks][e] = (float)x.e[e]; ss += f[ks][e] * f[ks][e]; dsum += (float)y.e[e] * (float)o.e[e]; }
             }
+            // delta = rowsum(dO o O) of this query: computed here (the pass needs dO anyway) and published for the dK/dV and
+            // bias-table passes, which run after this kernel -- no separate launch on the backward's critical chain
+            const float Dq = sum4g(dsum);                           // padding queries: dO = 0 => delta = 0 => dS = 0
+            if (qok[q] && fg == 0) delta[tq[q] * g.H + h] = Dq;
             float sc = g.scale * LOG2E;
             if (MODE == 0) sc = tau * LOG2E / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
 #pragma unroll
@@ -596,7 +584,6 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
                 for (int ks = 0; ks < HD / 32; ++ks) { U8 o; o.v = qf[q][ks]; *(uint4*)(qt_out + tq[q] * C + h * HD + ks * 32 + fg * 8) = o.u; }
             }
             L2q[q] = lse[lse0 + nqc[q]] * LOG2E;
-            const float Dq = qok[q] ? delta[tq[q] * g.H + h] : 0.f;      // padding queries: dO = 0 and delta = 0 => dS = 0
             negD[q] = (f32x4_t){-Dq, -Dq, -Dq, -Dq};
             eb[q] = ((unsigned)lse0 + (unsigned)nqc[q]) * NL;
 #pragma unroll
@@ -1223,9 +1210,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }
     const int Npad = (N + 31) / 32 * 32;
     const int T2 = mode == 0 ? (2 * ws - 1) * (2 * ws - 1) : 0;
-    if (passes & 1)
-        hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)cdiv(ntok * H * (hd / 8), 256)), dim3(256), 0, stream, (const bf16*)out, (const bf16*)dout,
-                           ws_delta, ntok, H, hd);
+    (void)ntok;          // delta = rowsum(dO o O) is computed (and written to ws_delta) by the dQ kernel
     const int split = am_split((int64_t)B * nW * H, (N + 15) / 16);
     dim3 grid(B * nW * H * split);
     const int ld = hd == 32 ? 32 : hd + 8;
@@ -1236,7 +1221,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         if (am_set_lds(attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>, bytes_q, "attn_bwd_dq_mfma_k")) return 1;                  \
         hipLaunchKernelGGL((attn_bwd_dq_mfma_k<HDV, MODEV, MASKV>), grid, dim3((HDV == 32 || MODEV == 1) ? 1024 : 512), bytes_q, stream, g, \
                            (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
-                           dlogit_scale, (bf16*)ws_qt, Npad, split);                                                                  \
+                           dlogit_scale, (bf16*)ws_qt, Npad, split, (const bf16*)out);                                                \
         if (am_set_lds(attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>, bytes_k, "attn_bwd_dkv_mfma_k")) return 1;                 \
         hipLaunchKernelGGL((attn_bwd_dkv_mfma_k<HDV, MODEV, MASKV>), grid, dim3((HDV == 32 || MODEV == 1) ? 1024 : 512), bytes_k, stream, g, \
                            (const bf16*)qkv, table16, logit_scale, valid, (const bf16*)dout, lse, ws_delta, (bf16*)dqkv,  \
