@@ -175,6 +175,9 @@ int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, 
 /* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,
                         float* table16, int T2, int H, mvuld_stream_t stream);
+/* ... for every block at once (the tables depend on parameters only: one launch after each optimizer step).  jobs: device array of
+ * {coords, W1, b1, W2, hidden (out), table16 (out), int64 T2, int64 H, int64 row0 = prefix sum of T2}. */
+int mvuld_cpb_table_fwd_batched(const void* jobs, int njobs, int64_t total_rows, mvuld_stream_t stream);
 int64_t mvuld_cpb_table_bwd_workspace_bytes(int T2, int H);   /* size of `ws` */
 int mvuld_cpb_table_bwd(const float* coords, const float* W2, const float* hidden, const float* table16,
                         const float* dtable16, float* dW1, float* db1, float* dW2, int T2, int H,

@@ -942,3 +942,42 @@ extern "C" int mvuld_qkv_bias_pack_batched(const void* jobs, int njobs, hipStrea
     MV_LAUNCH_CHECK("qkv_bias_pack_batched");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ continuous-position-bias tables of ALL blocks in one launch
+// The table of a SwinV2 block (16 * sigmoid(cpb_mlp(relative_coords_table)), swin_transformer_v2.py:159-163) depends on parameters
+// only: it is rebuilt for every block by one launch after each optimizer step instead of one launch per block on the forward's chain
+// of kernels (and, in inference, once instead of every forward).  Same arithmetic as cpb_fwd_k.
+struct CpbJob { const float* coords; const float* W1; const float* b1; const float* W2; float* hidden; float* table16; int64_t T2, H, row0; };
+__global__ __launch_bounds__(256) void cpb_fwd_batched_k(const CpbJob* __restrict__ jobs, int njobs) {
+    __shared__ float hid[512];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].row0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const CpbJob jb = jobs[lo];
+    const int i = (int)(blockIdx.x - jb.row0), H = (int)jb.H;
+    const float cy = jb.coords[2 * i], cx = jb.coords[2 * i + 1];
+    for (int j = threadIdx.x; j < 512; j += 256) {
+        const float v = fmaxf(jb.W1[2 * j] * cy + jb.W1[2 * j + 1] * cx + jb.b1[j], 0.f);
+        hid[j] = v;
+        jb.hidden[(int64_t)i * 512 + j] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int h = wv; h < H; h += 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = fmaf(hid[lane + 64 * k], jb.W2[h * 512 + lane + 64 * k], s);
+        s = wave_sum(s);
+        if (lane == 0) jb.table16[(int64_t)i * H + h] = 16.0f / (1.0f + __expf(-s));
+    }
+}
+// jobs: device array of {coords [T2,2], W1 [512,2], b1 [512], W2 [H,512], hidden [T2,512] (out), table16 [T2,H] (out), T2, H, row0 =
+// first block index of the job (prefix sum of T2)}; total_rows = sum of T2.
+extern "C" int mvuld_cpb_table_fwd_batched(const void* jobs, int njobs, int64_t total_rows, hipStream_t stream) {
+    MV_CHECK_ARG(jobs && njobs > 0 && total_rows > 0 && total_rows < 2147483647LL, "cpb_table_fwd_batched: bad args");
+    hipLaunchKernelGGL(cpb_fwd_batched_k, dim3((unsigned)total_rows), dim3(256), 0, stream, (const CpbJob*)jobs, njobs);
+    MV_LAUNCH_CHECK("cpb_table_fwd_batched");
+    return 0;
+}

@@ -89,12 +89,7 @@ class _SwinBlockFn(torch.autograd.Function):
             qkv = ops.linear_fwd(x, a.qkv.weight, bias=qb, xq=ops.fp8_take(x))
         else:
             qkv = ops.gemm_nt(x, ops.weight(a.qkv.weight, ad), bias=qb)
-        T2 = (2 * ws - 1) ** 2
-        hidden = torch.empty((T2, 512), dtype=torch.float32, device=x.device)
-        table16 = torch.empty((T2, H), dtype=torch.float32, device=x.device)
-        coords = a.relative_coords_table
-        call("cpb_table_fwd", ptr(coords), ptr(a.cpb_mlp[0].weight), ptr(a.cpb_mlp[0].bias), ptr(a.cpb_mlp[2].weight),
-             ptr(hidden), ptr(table16), T2, H)
+        hidden, table16 = blk._cpb_tables(x.device)
         ls = a.logit_scale.data.view(-1)
         geom = ops.AttnGeom(0, B, H, C // H, ws * ws, (res // ws) ** 2, res, ws, shift)
         att, lse = ops.attn_fwd(geom, qkv, table16, ls)
@@ -287,6 +282,23 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop=drop)
         self._batch = 0
         self._qb = None
+
+    def _cpb_tables(self, device):
+        """(hidden [T2, 512], table16 [T2, H]) of the continuous position bias (:159-163).  They depend on parameters only: cached
+        per weight epoch; store-resident blocks are rebuilt all together by one launch after the optimizer step."""
+        a = self.attn
+        ws, H = self.window_size, self.num_heads
+        T2 = (2 * ws - 1) ** 2
+        c = getattr(self, "_cpb", None)
+        if c is None or c[0].device != device:
+            c = self._cpb = (torch.empty((T2, 512), dtype=torch.float32, device=device), torch.empty((T2, H), dtype=torch.float32, device=device))
+            self._cpb_epoch = -1
+            ops.register_cpb(a, c[0], c[1], self)
+        if self._cpb_epoch != ops.WEIGHT_EPOCH[0]:
+            call("cpb_table_fwd", ptr(a.relative_coords_table), ptr(a.cpb_mlp[0].weight), ptr(a.cpb_mlp[0].bias), ptr(a.cpb_mlp[2].weight),
+                 ptr(c[0]), ptr(c[1]), T2, H)
+            self._cpb_epoch = ops.WEIGHT_EPOCH[0]
+        return c
 
     def _qkv_bias_buf(self, device):
         a = self.attn

@@ -235,6 +235,41 @@ def refresh_store_qkv_bias(store):
         o._qb_epoch = WEIGHT_EPOCH[0]
 
 
+def register_cpb(attn, hidden, table16, owner):
+    """A SwinV2 block's continuous-position-bias buffers join the store's job table (see refresh_store_cpb)."""
+    ps = (attn.cpb_mlp[0].weight, attn.cpb_mlp[0].bias, attn.cpb_mlp[2].weight)
+    st = getattr(ps[0], "_mv_store", None)
+    if st is None or any(getattr(p, "_mv_store", None) is not st for p in ps) or not hidden.is_cuda:
+        return
+    reg = st.__dict__.setdefault("_cpbjobs", {"list": [], "table": None, "rows": 0})
+    reg["list"].append((attn, hidden, table16, owner))
+    reg["table"] = None
+
+
+def refresh_store_cpb(store):
+    """All registered bias tables in one launch, right after the weight epoch moved."""
+    reg = getattr(store, "_cpbjobs", None)
+    if not reg or not reg["list"]:
+        return
+    live = [j for j in reg["list"] if getattr(j[3], "_cpb", None) is not None and j[3]._cpb[0] is j[1]]
+    if len(live) != len(reg["list"]):
+        reg["list"], reg["table"] = live, None
+        if not live:
+            return
+    if reg["table"] is None:
+        rows, r0 = [], 0
+        for a, hid, tab, _ in reg["list"]:
+            T2, H = tab.shape
+            rows.append([a.relative_coords_table.data_ptr(), a.cpb_mlp[0].weight.data.data_ptr(), a.cpb_mlp[0].bias.data.data_ptr(),
+                         a.cpb_mlp[2].weight.data.data_ptr(), hid.data_ptr(), tab.data_ptr(), T2, H, r0])
+            r0 += T2
+        reg["table"] = torch.tensor(rows, dtype=torch.int64).to(reg["list"][0][1].device)
+        reg["rows"] = r0
+    call("cpb_table_fwd_batched", ptr(reg["table"]), len(reg["list"]), reg["rows"])
+    for _, _, _, o in reg["list"]:
+        o._cpb_epoch = WEIGHT_EPOCH[0]
+
+
 def refresh_store_fp8(store):
     """Requantise every registered fp8 weight copy of a ParamStore (called right after the epoch moves, like the transposes)."""
     reg = getattr(store, "_q8jobs", None)

@@ -79,6 +79,7 @@ class ParamStore:
             ops.refresh_store_transposes(self)
             ops.refresh_store_fp8(self)
             ops.refresh_store_qkv_bias(self)
+            ops.refresh_store_cpb(self)
 
     def segment(self, prefix):
         """[(start, end)] flat ranges (one per group) covering the parameters whose name starts with `prefix`."""
@@ -151,6 +152,7 @@ class FusedAdamW(torch.optim.Optimizer):
         ops.refresh_store_transposes(st)
         ops.refresh_store_fp8(st)
         ops.refresh_store_qkv_bias(st)
+        ops.refresh_store_cpb(st)
 
     def host_hyper(self):
         """[n_groups, 3] {lr, 1 - b1^t, sqrt(1 - b2^t)} for the NEXT step() (t = steps taken + 1): what dev_hyper must hold before it."""
