@@ -19,6 +19,9 @@
 #include <stdlib.h>
 
 #define P_BN 256
+#ifndef P256_X
+#define P256_X 0      // timing experiments (tools/p256_variants.sh): bit 0 = epilogue without its stores, bit 1 = without GELU / dGELU math
+#endif
 #define P_BK 32
 #define P_STAGE_BYTES 32768
 #define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 const int j0 = 2 * jp;
                 // after the swaps this lane owns columns  nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8 .. + 7  of `row`
                 const int col = nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8;
-                const bool ok = row < g.M && col < g.N;
+                const bool ok = (P256_X & 1) ? false : (row < g.M && col < g.N);
                 float x[2][4];
                 if (AUX_IN) {
                     const uint4 zz = z[i][jp];
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                     for (int r = 0; r < 4; ++r) {
                         float t = alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
                         pre[h][r] = t;
-                        if (EPI == EPI_GELU) t = gelu_fast(t);
+                        if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
+                        else if (EPI == EPI_GELU) t = gelu_fast(t);
                         else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
                         else if (EPI == EPI_ADD_AUX) t += x[h][r];
                         v[h][r] = t;
@@ -279,6 +283,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][0], v[0][1]), pk_bf16(v[1][0], v[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][2], v[0][3]), pk_bf16(v[1][2], v[1][3]), false, false);
                     if (ok) *(uint4*)(C + (int64_t)row * g.ldc + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
                 if constexpr (FP8 && EPI == EPI_GELU) {
                     if (QE) {
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][2], pre[0][3]), pk_bf16(pre[1][2], pre[1][3]), false, false);
                     if (ok) *(uint4*)(aux + (int64_t)row * g.ldaux + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
             }
         }
