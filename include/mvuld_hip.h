@@ -190,6 +190,8 @@ int mvuld_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int mode
 int mvuld_elu_fwd(const void* x, void* y, int64_t n, int dtype, mvuld_stream_t stream);
 int mvuld_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t n, mvuld_stream_t stream);
 int mvuld_add(const void* a, const void* b, void* y, int64_t n, int dtype, mvuld_stream_t stream);
+/* y = a * b elementwise: the text x graph feature product of Multi_DefectModel_noGlobalImage (new_model.py:196) */
+int mvuld_mul(const void* a, const void* b, void* y, int64_t n, int dtype, mvuld_stream_t stream);
 /* y = x * keep / (1-p), keep = hash(seed, index) >= p: nn.Dropout of GraphModel.py:171-177, GATConv feat_drop,
  * RoBERTa hidden dropout; the same call with the same seed is the backward */
 int mvuld_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_offset, int dtype,

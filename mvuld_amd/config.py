@@ -160,6 +160,7 @@ _DEFAULTS = {
     "FUSED": {
         "ENABLE": True,            # train the three encoders in one step (north_star); False = reference-faithful head-only step
         "DTYPE": "bf16",           # activation storage: bf16 | fp32 | fp8 (= bf16 + forward encoder GEMMs in e4m3)
+        "HEAD": "Multi_DefectModel_new_GCN",   # any head class of models/{GraphModel,new_model,MotivationModel}.py (main_bigvul.py:124-129)
         "SYNTHETIC": True,         # synthetic Big-Vul-shaped data (there is no dataset on the box)
         "SYNTH_TRAIN": 256, "SYNTH_VAL": 64, "SYNTH_TEST": 64,
         "SEQ_LEN": 512, "NODES_LO": 150, "NODES_HI": 250,

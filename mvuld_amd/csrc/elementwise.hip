@@ -196,6 +196,20 @@ extern "C" int mvuld_add(const void* a, const void* b, void* y, int64_t n, int d
     return 0;
 }
 
+// y[i] = a[i] * b[i]   (feature product of the noGlobalImage ablation head, new_model.py:196; its backward is two more calls)
+template <typename T>
+__global__ void mul_k(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        stf(y + i, ldf(a + i) * ldf(b + i));
+}
+extern "C" int mvuld_mul(const void* a, const void* b, void* y, int64_t n, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(a && b && y && n > 0, "mul: bad args");
+    const int grid = (int)min((int64_t)8192, cdiv(n, 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mul_k<T>, dim3(grid), dim3(256), 0, stream, (const T*)a, (const T*)b, (T*)y, n));
+    MV_LAUNCH_CHECK("mul");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ dropout (counter-based, recomputable)
 __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;

@@ -83,7 +83,7 @@ def act_dtype_of(config):
 
 def build_fused_model(config):
     from mvuld_amd.models.fused import FusedMVulD
-    from mvuld_amd.models.GraphModel import Multi_DefectModel_new_GCN
+    from mvuld_amd.models.GraphModel import head_class
     from mvuld_amd.models.unixcoder import RobertaConfigLite
     ad = act_dtype_of(config)
     # FUSED.DTYPE fp8: bf16 activations and backward, the encoders' forward QKV / FFN products on the fp8 matrix cores
@@ -101,7 +101,11 @@ def build_fused_model(config):
                                intermediate_size=t.INTERMEDIATE, max_position_embeddings=t.MAX_POS,
                                hidden_dropout_prob=float(t.HIDDEN_DROPOUT), attention_probs_dropout_prob=attn_drop)
         return FusedMVulD(config, rc, ad)
-    return Multi_DefectModel_new_GCN(config=config, act_dtype=ad)
+    head = head_class(str(config.FUSED.HEAD))(config=config, act_dtype=ad)
+    for n, p in head.named_parameters():          # constructed by the reference, never used in forward: kept in the state dict, not trained
+        if n.startswith(tuple(head.unused_parameter_prefixes)):
+            p.requires_grad_(False)
+    return head
 
 
 def model_step_inputs(batch, device, pad_token_id=1, image_size=None):

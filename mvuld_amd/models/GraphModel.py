@@ -689,3 +689,212 @@ class Multi_DefectModel_NOGAT(nn.Module):
         hf = _L2NormMeanFn.apply(cast_to(v, torch.float32), B)
         all_feats = _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32))
         return linear_act(batch_norm(all_feats, self.final_fc_bn), self.final_fc.weight, self.final_fc.bias, None, torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ building blocks of the remaining ablation heads
+def _cast_in(v, ad):
+    return ops.cast(v.contiguous(), ad) if v.dtype != ad else v
+
+
+def _feature_branch(v, bn, fc, ad):
+    """BatchNorm1d -> Linear -> ELU of an encoder feature [B, C] (GraphModel.py:153-159)."""
+    return linear_act(batch_norm(_cast_in(v, ad), bn), fc.weight, fc.bias, "elu")
+
+
+def _gat_node_features(m, g, h, tr):
+    """GATConv x2 -> fc + ELU + dropout (GraphModel.py:167-171)."""
+    h = m.gat(g, h).view(h.shape[0], -1)
+    h = m.gat2(g, h).view(h.shape[0], -1)
+    return linear_act(h, m.fc.weight, m.fc.bias, "elu", None, m.p_mlp, tr)
+
+
+def _hidden_stack(layers, h, p, tr):
+    for hl in layers:
+        h = linear_act(h, hl.weight, hl.bias, "elu", None, p, tr)
+    return h
+
+
+def _gcn_readout(m, v, B):
+    """8 x Rs_GCN on node rows [B*100, 512] -> l2norm over nodes -> mean over the 100 slots (GraphModel.py:189-204)."""
+    v = cast_to(v, torch.float32 if m.chain_fp32 else m.act_dtype)
+    for i in range(1, 9):
+        v, _ = getattr(m, f"Rs_GCN_{i}").forward_rows(v, B)
+    return _L2NormMeanFn.apply(cast_to(v, torch.float32), B)
+
+
+def _padded_gcn_input(m, g, h, pos, B):
+    """pad to 100 nodes; bn_gat -> fc_gat -> ELU and bn_bbox -> fc_bbox -> ELU; concat -> node rows (GraphModel.py:182-188)."""
+    off = g.index()["node_offsets"]
+    h_i = _SegmentPadFn.apply(h, off, B, m.max_node)
+    pos_i = _SegmentPadFn.apply(pos, off, B, m.max_node)
+    h_i = linear_act(batch_norm(h_i, m.bn_gat), m.fc_gat.weight, m.fc_gat.bias, "elu")
+    fcb = m.fc_bbox2 if hasattr(m, "fc_bbox2") else m.fc_bbox
+    pos_i = linear_act(batch_norm(pos_i, m.bn_bbox), fcb.weight, fcb.bias, "elu")
+    return _ConcatColsFn.apply(h_i, pos_i).view(B * m.max_node, 512)
+
+
+def _bn_classifier(m, feats):
+    return linear_act(batch_norm(feats, m.final_fc_bn), m.final_fc.weight, m.final_fc.bias, None, torch.float32)
+
+
+class _MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.mul(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return ops.mul(dy, b), ops.mul(dy, a)
+
+
+def _head_common(m, config, act_dtype, p):
+    m.num_features, m.config, m.num_classes, m.act_dtype = 1024, config, config.MODEL.NUM_CLASSES, act_dtype
+    m.p_gat = m.p_mlp = m.p_hidden = p
+    m.max_node = 100
+    m.chain_fp32 = os.environ.get("MVULD_CHAIN_FP32", "1") == "1"
+
+
+def _add_gat(m, hfeat=512, embfeat=768, numheads=4):
+    m.gat = GATConv(in_feats=embfeat, out_feats=hfeat, num_heads=numheads, feat_drop=m.p_gat)
+    m.gat2 = GATConv(in_feats=hfeat * numheads, out_feats=hfeat, num_heads=numheads, feat_drop=m.p_gat)
+    m.fc = nn.Linear(hfeat * numheads, hfeat)
+
+
+def _add_gcn(m):
+    for i in range(1, 9):
+        setattr(m, f"Rs_GCN_{i}", Rs_GCN(in_channels=512, inter_channels=512))
+
+
+class Multi_DefectModel_GATPOS(nn.Module):
+    """Positions joined to the node embeddings BEFORE the GAT (reference GraphModel.py:721-827): ELU(fc_gat 768->720) ++ ELU(fc_bbox 4->48)
+    -> GATConv x2 -> fc -> 8 hidden -> pad to 100 -> bn_gat -> hfc -> ELU -> mean over the 100 slots."""
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        _head_common(self, config, act_dtype, 0.1)
+        _add_gat(self)
+        self.fconly = nn.Linear(768, 512)
+        self.hidden = nn.ModuleList([nn.Linear(512, 512) for _ in range(8)])
+        self.bn_text = nn.BatchNorm1d(768)
+        self.fc_text = nn.Linear(768, 512)
+        self.swinbn = nn.BatchNorm1d(1024)
+        self.swinfc = nn.Linear(1024, 512)
+        self.hbn = nn.BatchNorm1d(512)
+        self.hfc = nn.Linear(512, 512)
+        self.bn_gat = nn.BatchNorm1d(self.max_node)
+        self.fc_gat = nn.Linear(768, 720)
+        self.bn_bbox = nn.BatchNorm1d(self.max_node)
+        self.fc_bbox = nn.Linear(4, 48)
+        self.final_fc = nn.Linear(512 * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(512 * 3)
+        self.unused_parameter_prefixes = ("fconly.", "hbn.", "bn_bbox.")
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad, tr, B = self.act_dtype, self.training, g.batch_size
+        ops.USE_SPLIT3[0] = False
+        h = g.ndata["_UNIX_NODE_EMB"]
+        hip.require_gpu(h, img_embedding, func_text_embedding)
+        x = _feature_branch(img_embedding, self.swinbn, self.swinfc, ad)
+        t = _feature_branch(func_text_embedding, self.bn_text, self.fc_text, ad)
+        h = linear_act(_cast_in(h, ad), self.fc_gat.weight, self.fc_gat.bias, "elu")                      # [N,720]
+        pos = linear_act(_cast_in(g.ndata["pos_emb"], ad), self.fc_bbox.weight, self.fc_bbox.bias, "elu")  # [N,48]
+        h = _ConcatColsFn.apply(h, pos)
+        h = _hidden_stack(self.hidden, _gat_node_features(self, g, h, tr), self.p_hidden, tr)
+        g.ndata['HGATOUTPUT'] = h
+        g.ndata['HFGATOUTPUT'] = pos
+        h_i = batch_norm(_SegmentPadFn.apply(h, g.index()["node_offsets"], B, self.max_node), self.bn_gat)
+        h_i = linear_act(h_i, self.hfc.weight, self.hfc.bias, "elu").view(B * self.max_node, 512)
+        slots = (torch.arange(B + 1, dtype=torch.int32) * self.max_node).to(h_i.device)
+        hf = cast_to(_MeanNodesFn.apply(h_i, slots, B), torch.float32)
+        return _bn_classifier(self, _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32)))
+
+
+class _MlpGcnHead(nn.Module):
+    """The reference's NOGAT2 / NOGAT3 / NOGAT4 heads (GraphModel.py:1053-1382): node MLP instead of the GAT in front of the Rs_GCN chain.
+      NOGAT2: fconly(768->512) -> 8 hidden; raw positions padded beside them            (the full head with the GAT swapped for fconly)
+      NOGAT3: as NOGAT2, positions through fc_bbox(4->128) + 8 pos_hidden(128) per node, fc_bbox2(128->32) after the padding
+      NOGAT4: fconly(768->480) ++ ELU(fc_bbox 4->32) per node -> 8 hidden(512); after padding bn_gat -> fc_gat(512->512) -> ELU only"""
+    VARIANT = 2
+
+    def __init__(self, config, pretrained=True, attention=True, act_dtype=torch.bfloat16):
+        super().__init__()
+        _head_common(self, config, act_dtype, 0.2)
+        v = self.VARIANT
+        self.fconly = nn.Linear(768, 480 if v == 4 else 512)
+        self.hidden = nn.ModuleList([nn.Linear(512, 512) for _ in range(8)])
+        if v == 3:
+            self.pos_hidden = nn.ModuleList([nn.Linear(128, 128) for _ in range(8)])
+        _add_gcn(self)
+        self.bn_text = nn.BatchNorm1d(768)
+        self.ln_text = nn.LayerNorm(768)
+        self.fc_text = nn.Linear(768, 512)
+        self.bn_gat = nn.BatchNorm1d(self.max_node)
+        self.fc_gat = nn.Linear(512, 512 if v == 4 else 480)
+        if v != 4:
+            self.bn_bbox = nn.BatchNorm1d(self.max_node)
+        self.fc_bbox = nn.Linear(4, 128 if v == 3 else 32)
+        if v == 3:
+            self.fc_bbox2 = nn.Linear(128, 32)
+        self.swinbn = nn.BatchNorm1d(1024)
+        self.swinfc = nn.Linear(1024, 512)
+        self.hbn = nn.BatchNorm1d(512)
+        self.hln = nn.LayerNorm(512)
+        self.hfc = nn.Linear(512, 512)
+        self.final_fc = nn.Linear(512 * 3, self.num_classes)
+        self.final_fc_bn = nn.BatchNorm1d(512 * 3)
+        self.unused_parameter_prefixes = ("ln_text.", "hbn.", "hln.", "hfc.")
+
+    def forward(self, g, img_embedding, func_text_embedding):
+        ad, tr, B, v = self.act_dtype, self.training, g.batch_size, self.VARIANT
+        ops.USE_SPLIT3[0] = ad == torch.bfloat16
+        h = g.ndata["_UNIX_NODE_EMB"]
+        hip.require_gpu(h, img_embedding, func_text_embedding)
+        x = _feature_branch(img_embedding, self.swinbn, self.swinfc, ad)
+        t = _feature_branch(func_text_embedding, self.bn_text, self.fc_text, ad)
+        h = linear_act(_cast_in(h, ad), self.fconly.weight, self.fconly.bias, "elu", None, self.p_mlp, tr)
+        pos = _cast_in(g.ndata["pos_emb"], ad)
+        hfg = g.ndata["pos_emb"]
+        if v == 4:
+            h = _ConcatColsFn.apply(h, linear_act(pos, self.fc_bbox.weight, self.fc_bbox.bias, "elu"))
+        h = _hidden_stack(self.hidden, h, self.p_hidden, tr)
+        if v == 3:
+            pos = linear_act(pos, self.fc_bbox.weight, self.fc_bbox.bias, "elu")
+            pos = hfg = _hidden_stack(self.pos_hidden, pos, self.p_hidden, tr)
+        g.ndata['HGATOUTPUT'] = h
+        g.ndata['HFGATOUTPUT'] = hfg
+        if v == 4:
+            h_i = batch_norm(_SegmentPadFn.apply(h, g.index()["node_offsets"], B, self.max_node), self.bn_gat)
+            rows = linear_act(h_i, self.fc_gat.weight, self.fc_gat.bias, "elu").view(B * self.max_node, 512)
+        else:
+            rows = _padded_gcn_input(self, g, h, pos, B)
+        hf = _gcn_readout(self, rows, B)
+        return _bn_classifier(self, _ConcatColsFn.apply(cast_to(x, torch.float32), hf, cast_to(t, torch.float32)))
+
+
+class Multi_DefectModel_NOGAT2(_MlpGcnHead):
+    """(reference GraphModel.py:1277-1382)"""
+    VARIANT = 2
+
+
+class Multi_DefectModel_NOGAT3(_MlpGcnHead):
+    """(reference GraphModel.py:1053-1170)"""
+    VARIANT = 3
+
+
+class Multi_DefectModel_NOGAT4(_MlpGcnHead):
+    """(reference GraphModel.py:1173-1274)"""
+    VARIANT = 4
+
+
+def head_class(name):
+    """The head class of that name from GraphModel / new_model / MotivationModel (the reference picks one by editing
+    main_bigvul.py:124-129; here it is the FUSED.HEAD / --opts key)."""
+    import importlib
+    for mod in ("GraphModel", "new_model", "MotivationModel"):
+        m = importlib.import_module("mvuld_amd.models." + mod)
+        if hasattr(m, name) and name.startswith("Multi_DefectModel"):
+            return getattr(m, name)
+    raise KeyError(f"unknown head {name!r}")

@@ -25,7 +25,10 @@ class FusedMVulD(nn.Module):
             p.requires_grad_(False)
         for p in self.swin.head.parameters():
             p.requires_grad_(False)
-        self.head = Multi_DefectModel_new_GCN(config, act_dtype=act_dtype)
+        from .GraphModel import head_class
+        head_name = str(getattr(getattr(config, "FUSED", None), "HEAD", "") or "Multi_DefectModel_new_GCN")
+        self.head = head_class(head_name)(config, act_dtype=act_dtype)
+        self._split_head = hasattr(self.head, "forward_graph")     # the full head's graph branch can run beside the encoders
         self._side = None
         self._gs = None
         self._tn_budget = -1
@@ -33,7 +36,7 @@ class FusedMVulD(nn.Module):
         self._inflight = []
         self.max_steps_in_flight = 2          # 0 = do not throttle the host (bench.py's enqueue-cost measurement)
         for n, p in self.head.named_parameters():
-            if n.startswith(self.head.unused_parameter_prefixes):
+            if n.startswith(tuple(self.head.unused_parameter_prefixes)):
                 p.requires_grad_(False)
 
     def no_weight_decay(self):
@@ -86,7 +89,7 @@ class FusedMVulD(nn.Module):
             ops.on_backward_done("unixcoder", None, key="fused-join")
             img = self.swin.forward_features(images)                   # [B,1024]
             _, txt = self.unixcoder.get_xcode_vec(source_ids, seq_lens)  # [B,768]
-            hfeat = self.head.forward_graph(g)
+            hfeat = self.head.forward_graph(g) if self._split_head else None
         else:
             main = torch.cuda.current_stream(images.device)
             # Bound how far the host may run ahead of the GPU: tensors handed to another stream (record_stream) cannot be reused
@@ -111,7 +114,7 @@ class FusedMVulD(nn.Module):
             ops.WGRAD_STREAM[0] = (main.cuda_stream, self._wg) if use_wg else None
             side.wait_stream(main)
             gst = side
-            if os.environ.get("MVULD_GRAPH_STREAM", "1") != "0":
+            if self._split_head and os.environ.get("MVULD_GRAPH_STREAM", "1") != "0":
                 if self._gs is None:
                     self._gs = torch.cuda.Stream(device=images.device)
                 gst = self._gs
@@ -127,13 +130,16 @@ class FusedMVulD(nn.Module):
             img = self.swin.forward_features(images)
             # The graph branch gets a stream of its own: ~600 small, latency-bound launches per step that used to queue in front of
             # (forward) and behind (backward: 6 ms) the text encoder on the side stream, which had become the last to finish.
-            with torch.cuda.stream(gst):
-                hfeat = self.head.forward_graph(g)
+            hfeat = None
+            if self._split_head:
+                with torch.cuda.stream(gst):
+                    hfeat = self.head.forward_graph(g)
             main.wait_stream(side)
             if gst is not side:
                 main.wait_stream(gst)
             txt.record_stream(main)
-            hfeat.record_stream(main)
+            if hfeat is not None:
+                hfeat.record_stream(main)
 
             def join():                                                # runs inside backward, on the side stream
                 ev = torch.cuda.Event()
@@ -141,4 +147,6 @@ class FusedMVulD(nn.Module):
                 main.wait_event(ev)
             ops.on_backward_done("unixcoder", join, key="fused-join")
         g.ndata["_FUNC_EMB"] = txt                                     # (per-node repeat is dead in the reference head)
+        if not self._split_head:                                       # an ablation head (FUSED.HEAD): whole head after the join
+            return self.head(g, img, txt)
         return self.head.forward_join(g, img, txt, hfeat)

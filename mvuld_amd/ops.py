@@ -609,6 +609,12 @@ def add(a, b):
     return y
 
 
+def mul(a, b):
+    y = torch.empty_like(a)
+    call("mul", ptr(a), ptr(b), ptr(y), a.numel(), dt(a))
+    return y
+
+
 # Device-resident step counter (int64 [1]) mixed into every RNG kernel's seed, or None.  A hipGraph-captured training step sets it
 # (graph_step.GraphedTrainStep): host seeds are frozen into the captured launches, the counter advances inside the graph.
 RNG_OFFSET = [None]

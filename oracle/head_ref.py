@@ -224,3 +224,167 @@ def head_nogat_forward(sd, batch_num_nodes, node_emb, pos_emb, img_embedding, fu
     gg = gg / gg.pow(2).sum(dim=1, keepdim=True).sqrt()
     allf = torch.cat([x, gg.mean(dim=1), t], dim=1)
     return F.linear(_bn(sd, P + "final_fc_bn.", allf, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+# ------------------------------------------------------------------------------------------------ the remaining ablation heads
+def _img_branch(sd, P, img, training):
+    return F.elu(F.linear(_bn(sd, P + "swinbn.", img, training), sd[P + "swinfc.weight"], sd[P + "swinfc.bias"]))
+
+
+def _text_branch(sd, P, txt, training):
+    return F.elu(F.linear(_bn(sd, P + "bn_text.", txt, training), sd[P + "fc_text.weight"], sd[P + "fc_text.bias"]))
+
+
+def _lin_elu(sd, p, x):
+    return F.elu(F.linear(x, sd[p + "weight"], sd[p + "bias"]))
+
+
+def _gat_mlp(sd, P, x, src, dst):
+    """GATConv x2 -> fc + ELU -> 8 hidden + ELU (GraphModel.py:167-177)."""
+    h = gat_conv(sd, P + "gat.", x, src, dst)
+    h = gat_conv(sd, P + "gat2.", h.reshape(h.shape[0], -1), src, dst)
+    h = _lin_elu(sd, P + "fc.", h.reshape(h.shape[0], -1))
+    for i in range(8):
+        h = _lin_elu(sd, P + f"hidden.{i}.", h)
+    return h
+
+
+def _gcn_l2_mean(sd, P, rows, training):
+    """[B, 100, 512] -> 8 x Rs_GCN -> l2norm over the node axis -> mean over nodes (GraphModel.py:189-204)."""
+    gg = rows.permute(0, 2, 1)
+    for i in range(1, 9):
+        gg, _ = rs_gcn(sd, P + f"Rs_GCN_{i}.", gg, training)
+    gg = gg.permute(0, 2, 1)
+    gg = gg / gg.pow(2).sum(dim=1, keepdim=True).sqrt()
+    return gg.mean(dim=1)
+
+
+def _pad_bn_fc(sd, P, h, pos, bnn, training, fc_pos="fc_bbox."):
+    h_i = _lin_elu(sd, P + "fc_gat.", _bn(sd, P + "bn_gat.", unbatch_pad(h, bnn), training))
+    pos_i = _lin_elu(sd, P + fc_pos, _bn(sd, P + "bn_bbox.", unbatch_pad(pos, bnn), training))
+    return torch.cat([h_i, pos_i], dim=2)
+
+
+def _final_bn_fc(sd, P, feats, training):
+    return F.linear(_bn(sd, P + "final_fc_bn.", feats, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def head_gatpos_forward(sd, src, dst, batch_num_nodes, node_emb, pos_emb, img, txt, training=False, prefix=""):
+    """Multi_DefectModel_GATPOS.forward (GraphModel.py:773-827)."""
+    P = prefix
+    x, t = _img_branch(sd, P, img, training), _text_branch(sd, P, txt, training)
+    h = torch.cat([_lin_elu(sd, P + "fc_gat.", node_emb), _lin_elu(sd, P + "fc_bbox.", pos_emb)], dim=1)
+    h = _gat_mlp(sd, P, h, src, dst)
+    h_i = _lin_elu(sd, P + "hfc.", _bn(sd, P + "bn_gat.", unbatch_pad(h, batch_num_nodes), training))
+    return _final_bn_fc(sd, P, torch.cat([x, h_i.mean(dim=1), t], dim=1), training)
+
+
+def head_mlp_gcn_forward(sd, variant, batch_num_nodes, node_emb, pos_emb, img, txt, training=False, prefix=""):
+    """Multi_DefectModel_NOGAT2 / NOGAT3 / NOGAT4 .forward (GraphModel.py:1334-1382, 1118-1170, 1226-1274); variant in {2, 3, 4}."""
+    P = prefix
+    x, t = _img_branch(sd, P, img, training), _text_branch(sd, P, txt, training)
+    h = _lin_elu(sd, P + "fconly.", node_emb)
+    pos = pos_emb
+    if variant == 4:
+        h = torch.cat([h, _lin_elu(sd, P + "fc_bbox.", pos_emb)], dim=1)
+    for i in range(8):
+        h = _lin_elu(sd, P + f"hidden.{i}.", h)
+    if variant == 3:
+        pos = _lin_elu(sd, P + "fc_bbox.", pos_emb)
+        for i in range(8):
+            pos = _lin_elu(sd, P + f"pos_hidden.{i}.", pos)
+    if variant == 4:
+        rows = _lin_elu(sd, P + "fc_gat.", _bn(sd, P + "bn_gat.", unbatch_pad(h, batch_num_nodes), training))
+    else:
+        rows = _pad_bn_fc(sd, P, h, pos, batch_num_nodes, training, "fc_bbox2." if variant == 3 else "fc_bbox.")
+    return _final_bn_fc(sd, P, torch.cat([x, _gcn_l2_mean(sd, P, rows, training), t], dim=1), training)
+
+
+def _full_graph_branch(sd, P, src, dst, bnn, node_emb, pos_emb, training):
+    h = _gat_mlp(sd, P, node_emb, src, dst)
+    return _gcn_l2_mean(sd, P, _pad_bn_fc(sd, P, h, pos_emb, bnn, training), training)
+
+
+def head_noglobalimage_forward(sd, src, dst, batch_num_nodes, node_emb, pos_emb, txt, training=False, prefix=""):
+    """Multi_DefectModel_noGlobalImage.forward (new_model.py:147-199): text feature x graph feature."""
+    P = prefix
+    hf = _full_graph_branch(sd, P, src, dst, batch_num_nodes, node_emb, pos_emb, training)
+    return _final_bn_fc(sd, P, _text_branch(sd, P, txt, training) * hf, training)
+
+
+def head_nofunc_forward(sd, src, dst, batch_num_nodes, node_emb, pos_emb, img, training=False, prefix=""):
+    """Multi_DefectModel_noFunc.forward (new_model.py:269-326): image feature ++ graph feature."""
+    P = prefix
+    hf = _full_graph_branch(sd, P, src, dst, batch_num_nodes, node_emb, pos_emb, training)
+    return _final_bn_fc(sd, P, torch.cat([_img_branch(sd, P, img, training), hf], dim=1), training)
+
+
+def head_single_modality_forward(sd, feat, prefix=""):
+    """Multi_DefectModel_Image / _FuncText .forward (MotivationModel.py:105-107, 143-145): final_fc on the raw encoder feature."""
+    return F.linear(feat, sd[prefix + "final_fc.weight"], sd[prefix + "final_fc.bias"])
+
+
+def head_graph_forward(sd, src, dst, batch_num_nodes, node_emb, pos_emb, training=False, prefix=""):
+    """Multi_DefectModel_Graph.forward (MotivationModel.py:205-256): the full graph branch, final_fc without BatchNorm."""
+    hf = _full_graph_branch(sd, prefix, src, dst, batch_num_nodes, node_emb, pos_emb, training)
+    return F.linear(hf, sd[prefix + "final_fc.weight"], sd[prefix + "final_fc.bias"])
+
+
+def head_graph1_forward(sd, batch_num_nodes, node_emb, training=False, prefix=""):
+    """Multi_DefectModel_Graph1.forward (MotivationModel.py:306-348): node MLP -> pad -> bn_gat / fc_gat / ELU -> Rs_GCN x8."""
+    P = prefix
+    h = _lin_elu(sd, P + "fconly.", node_emb)
+    for i in range(8):
+        h = _lin_elu(sd, P + f"hidden.{i}.", h)
+    rows = _lin_elu(sd, P + "fc_gat.", _bn(sd, P + "bn_gat.", unbatch_pad(h, batch_num_nodes), training))
+    return F.linear(_gcn_l2_mean(sd, P, rows, training), sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def head_graph2_forward(sd, src, dst, batch_num_nodes, node_emb, training=False, prefix=""):
+    """Multi_DefectModel_Graph2.forward (MotivationModel.py:389-426): GAT + MLP -> dgl.mean_nodes -> hbn / hfc / ELU -> final_fc."""
+    P = prefix
+    h = _gat_mlp(sd, P, node_emb, src, dst)
+    off = [0] + torch.cumsum(torch.as_tensor(batch_num_nodes), 0).tolist()
+    hmean = torch.stack([h[off[b]:off[b + 1]].mean(0) for b in range(len(off) - 1)])
+    hf = _lin_elu(sd, P + "hfc.", _bn(sd, P + "hbn.", hmean, training))
+    return F.linear(hf, sd[P + "final_fc.weight"], sd[P + "final_fc.bias"])
+
+
+def ablation_forward(name, sd, g_src, g_dst, bnn, node_emb, pos_emb, img, txt, training=False, prefix=""):
+    """Dispatch by the reference class name (without the ``Multi_DefectModel`` prefix: "", "_noGraph", "_000", ..., "_Graph2")."""
+    a = dict(training=training, prefix=prefix)
+    rq3 = {"_000": (0, 0, 0), "_001": (0, 0, 1), "_100": (1, 0, 0), "_110": (1, 1, 0), "_011": (0, 1, 1)}
+    if name == "":
+        return head_gat_mean_forward(sd, g_src, g_dst, bnn, node_emb, img, txt, **a)
+    if name == "_noGraph":
+        return head_nograph_forward(sd, img, txt, **a)
+    if name in rq3:
+        return head_rq3_forward(sd, *map(bool, rq3[name]), g_src, g_dst, bnn, node_emb, pos_emb, img, txt, **a)
+    if name == "_NOGAT":
+        return head_nogat_forward(sd, bnn, node_emb, pos_emb, img, txt, **a)
+    if name in ("_NOGAT2", "_NOGAT3", "_NOGAT4"):
+        return head_mlp_gcn_forward(sd, int(name[-1]), bnn, node_emb, pos_emb, img, txt, **a)
+    if name == "_GATPOS":
+        return head_gatpos_forward(sd, g_src, g_dst, bnn, node_emb, pos_emb, img, txt, **a)
+    if name == "_noGlobalImage":
+        return head_noglobalimage_forward(sd, g_src, g_dst, bnn, node_emb, pos_emb, txt, **a)
+    if name == "_noFunc":
+        return head_nofunc_forward(sd, g_src, g_dst, bnn, node_emb, pos_emb, img, **a)
+    if name == "_Image":
+        return head_single_modality_forward(sd, img, prefix)
+    if name == "_FuncText":
+        return head_single_modality_forward(sd, txt, prefix)
+    if name == "_Graph":
+        return head_graph_forward(sd, g_src, g_dst, bnn, node_emb, pos_emb, **a)
+    if name == "_Graph1":
+        return head_graph1_forward(sd, bnn, node_emb, **a)
+    if name == "_Graph2":
+        return head_graph2_forward(sd, g_src, g_dst, bnn, node_emb, **a)
+    raise KeyError(name)
+
+
+ABLATION_HEADS = {   # reference module -> class-name suffixes
+    "GraphModel": ["", "_noGraph", "_000", "_001", "_100", "_110", "_GATPOS", "_011", "_NOGAT", "_NOGAT3", "_NOGAT4", "_NOGAT2"],
+    "new_model": ["_noGlobalImage", "_noFunc"],
+    "MotivationModel": ["_Image", "_FuncText", "_Graph", "_Graph1", "_Graph2"],
+}

@@ -76,6 +76,10 @@ def install_standins():
         def number_of_nodes(self):
             return int(sum(self.bnn))
 
+        def local_scope(self):                      # dgl's scoped ndata: the ablation heads only add a temporary key inside it
+            import contextlib
+            return contextlib.nullcontext()
+
     class GATConv(nn.Module):
         def __init__(self, in_feats, out_feats, num_heads, feat_drop=0.0, attn_drop=0.0, negative_slope=0.2,
                      residual=False, activation=None, allow_zero_in_degree=False, bias=True):
@@ -97,7 +101,13 @@ def install_standins():
             out.append(G(None, None, [n], {k: v[o:o + n] for k, v in g.ndata.items()})); o += n
         return out
 
-    dgl.unbatch = unbatch; dgl.G = G
+    def mean_nodes(g, key):                         # documented dgl.mean_nodes: per-graph mean of a node feature
+        h, out, o = g.ndata[key], [], 0
+        for n in g.bnn:
+            out.append(h[o:o + n].mean(0)); o += n
+        return torch.stack(out)
+
+    dgl.unbatch = unbatch; dgl.G = G; dgl.mean_nodes = mean_nodes
     dpt.GATConv = GATConv; dpt.GraphConv = nn.Identity; dpt.GatedGraphConv = nn.Identity
     dgl.nn = dnn; dnn.pytorch = dpt
     sys.modules.update({"dgl": dgl, "dgl.nn": dnn, "dgl.nn.pytorch": dpt})
@@ -230,6 +240,46 @@ ROB_CASES = {
     "roberta_base512": (dict(), 512, [512, 301]),
 }
 
+def gen_ablation_heads(out, dgl):
+    """Every ablation / motivation head of the reference (GraphModel.py:214-1382, new_model.py, MotivationModel.py), eval and train
+    mode, dropouts off: the reference class's own forward on the synthetic weights (keyed "<class>/<state-dict key>") next to the
+    oracle restatement; also checks that the build's class of the same name has the same state-dict keys and shapes."""
+    sys.path.insert(0, REF)
+    import importlib
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    g, img, txt = head_inputs()
+    bnn = g.batch_num_nodes()
+    res = {}
+    for modname, suffixes in head_ref.ABLATION_HEADS.items():
+        ref_mod = importlib.import_module("models." + modname)
+        our_mod = importlib.import_module("mvuld_amd.models." + modname)
+        for sfx in suffixes:
+            name = "Multi_DefectModel" + sfx
+            m = getattr(ref_mod, name)(cfg)
+            for mod in m.modules():
+                if isinstance(mod, nn.Dropout):
+                    mod.p = 0.0
+            sd = load_synth(m, prefix=name + "/")
+            ours = getattr(our_mod, name)(cfg).state_dict()
+            ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            assert ref_shapes == {k: tuple(v.shape) for k, v in ours.items()}, (name, set(ref_shapes) ^ set(ours))
+            bare = {k[len(name) + 1:]: v for k, v in sd.items()}
+            for mode in ("eval", "train"):
+                m.train(mode == "train")
+                m.load_state_dict(bare, strict=False)
+                rg = dgl.G(g.src, g.dst, bnn.tolist(), {"_UNIX_NODE_EMB": g.ndata["_UNIX_NODE_EMB"], "pos_emb": g.ndata["pos_emb"],
+                                                        "_FUNC_EMB": txt.repeat_interleave(bnn, 0)})
+                with torch.no_grad():
+                    y_ref = m(rg, img, txt)
+                    y_orc = head_ref.ablation_forward(sfx, bare, g.src, g.dst, bnn, g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt,
+                                                      training=(mode == "train"))
+                e = rel_err(y_orc, y_ref)
+                print(f"[{name}/{mode}] logits {y_ref[0].tolist()} rel={e:.2e}")
+                assert e < 2e-5, (name, mode, e)
+                res[f"{name}/{mode}"] = y_ref.numpy()
+    np.savez(os.path.join(out, "ablation_heads.npz"), **res)
+
+
 
 def rob_ids(cfg, L, lens, tag):
     rows = []
@@ -292,6 +342,8 @@ def main():
         gen_rsgcn(a.out)
     if not w or "head" in w:
         gen_head(a.out, dgl)
+    if not w or "ablation_heads" in w:
+        gen_ablation_heads(a.out, dgl)
 
 
 if __name__ == "__main__":

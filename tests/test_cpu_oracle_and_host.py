@@ -67,6 +67,36 @@ def test_oracle_head_and_rsgcn_match_reference_golden(mode):
     assert rel(y, torch.from_numpy(gd[f"y_{mode}"])) < 1e-5 and rel(R, torch.from_numpy(gd[f"R_{mode}"])) < 1e-5
 
 
+def _ablation_cases():
+    from oracle import head_ref
+    return [(mod, sfx) for mod, sfxs in head_ref.ABLATION_HEADS.items() for sfx in sfxs]
+
+
+@pytest.mark.parametrize("mod,sfx", _ablation_cases())
+def test_oracle_ablation_heads_match_reference_golden(mod, sfx):
+    """All 19 ablation / motivation heads of the reference (GraphModel.py:214-1382, new_model.py, MotivationModel.py): the oracle
+    restatement reproduces the logits the reference classes themselves gave (tests/golden/make_golden.py, eval and train mode), on
+    weights rebuilt from the build's class of the same name -- whose state-dict keys and shapes the generator checked against the
+    reference's."""
+    import importlib
+    import types
+    from oracle import head_ref
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.graph import batch
+    name = "Multi_DefectModel" + sfx
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    shapes = {k: tuple(v.shape) for k, v in getattr(importlib.import_module("mvuld_amd.models." + mod), name)(cfg).state_dict().items()}
+    sd = {k: synth.synth_param(name + "/" + k, s) for k, s in shapes.items()}
+    g = batch([synthetic.make_graph(2000 + i, n, n) for i, n in enumerate([60, 100, 130, 217])])
+    img, txt = synth.tensor("head/img", (4, 1024), -1, 1), synth.tensor("head/txt", (4, 768), -1, 1)
+    gd = golden("ablation_heads")
+    for mode in ("eval", "train"):
+        with torch.no_grad():
+            lg = head_ref.ablation_forward(sfx, sd, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt,
+                                           training=(mode == "train"))
+        assert float((lg - torch.from_numpy(gd[f"{name}/{mode}"])).abs().max()) < 2e-5, (name, mode)
+
+
 def test_oracle_gat_softmax_properties():
     """edge softmax sums to one over the incoming edges of every destination, multi-edges counted separately."""
     from oracle import head_ref

@@ -1155,3 +1155,85 @@ def test_rq3_ablation_heads_vs_oracle(gpu, dtype, name, flags):
             assert ps[k].grad is not None and p.grad is not None, k
             worst = max(worst, float((p.grad.float().cpu() - ps[k].grad).norm() / (ps[k].grad.norm() + 1e-12)))
         assert worst < 3e-3, worst
+
+
+def _all_ablation_cases():
+    from oracle import head_ref
+    return [(mod, sfx) for mod, sfxs in head_ref.ABLATION_HEADS.items() for sfx in sfxs]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mod,sfx", _all_ablation_cases())
+def test_every_ablation_head_vs_reference_golden_and_oracle(gpu, dtype, mod, sfx):
+    """SURVEY 8f row 4, complete: each of the reference's 19 ablation / motivation heads (GraphModel.py:214-1382, new_model.py,
+    MotivationModel.py) as a class of the same name, module, constructor, forward signature and state-dict keys on the HIP kernels.
+    Eval logits against the logits the REFERENCE class gave on the same synthetic weights (tests/golden/ablation_heads.npz) and, in
+    fp32, parameter gradients against the oracle restatement (itself pinned to those goldens by the CPU suite)."""
+    import importlib
+    from oracle import head_ref
+    from mvuld_amd import ops
+    name = "Multi_DefectModel" + sfx
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    m = getattr(importlib.import_module("mvuld_amd.models." + mod), name)(cfg, act_dtype=dtype)
+    sd, _ = load_synth_into(m, prefix=name + "/")
+    sd = {k[len(name) + 1:]: v for k, v in sd.items()}
+    m = m.to(gpu).eval()
+    ops.bump_weight_epoch()
+    g, img, txt = _head_inputs()
+    ps = {k: v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone() for k, v in sd.items()}
+    ref = head_ref.ablation_forward(sfx, ps, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt)
+    gold = torch.from_numpy(golden("ablation_heads")[f"{name}/eval"])
+    assert float((ref.detach() - gold).abs().max()) < 2e-5
+    w = synth.tensor("abl/w", tuple(ref.shape), -1, 1)
+    (ref * w).sum().backward()
+    lg = m(g.to(gpu), img.to(gpu), txt.to(gpu))
+    (lg * w.to(gpu)).sum().backward()
+    torch.cuda.synchronize()
+    err = float((lg.float().cpu() - gold).abs().max())
+    print(f"[{name} eval {dtype}] logits abs err vs reference golden {err:.3e} (scale {float(gold.abs().max()):.2f})")
+    assert err < (1e-3 if dtype == torch.float32 else 2e-2)
+    if dtype == torch.float32:
+        worst = 0.0
+        for k, p in m.named_parameters():
+            if k.startswith(tuple(m.unused_parameter_prefixes)):
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            assert ps[k].grad is not None and p.grad is not None, k
+            worst = max(worst, float((p.grad.float().cpu() - ps[k].grad).norm() / (ps[k].grad.norm() + 1e-12)))
+        assert worst < 3e-3, (name, worst)
+
+
+@pytest.mark.parametrize("head,fused", [("Multi_DefectModel_noFunc", True), ("Multi_DefectModel_NOGAT2", True), ("Multi_DefectModel_Graph2", False)])
+def test_ablation_head_selected_by_config_trains(gpu, head, fused):
+    """FUSED.HEAD picks the head class (the reference edits main_bigvul.py:124-129 for that): the fused model (tiny plumbing encoders) or
+    the head-only model with an ablation head runs whole train steps -- forward, backward through the encoders, clip, AdamW -- and the
+    loss on one fixed batch goes down."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    from mvuld_amd.data import synthetic
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16", "FUSED.HEAD", head, "FUSED.ENABLE", str(fused), "TRAIN.BASE_LR", "1e-3"],
+                                              batch_size=8, local_rank=0))
+    torch.manual_seed(11)
+    model = build_fused_model(config).to(gpu).train()
+    assert type(model.head if fused else model).__name__ == head
+    opt = build_optimizer(config, model)
+    f = config.FUSED
+    g, images, ids, labels = synthetic.make_batch(list(range(40, 48)), config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    g, images, ids, labels = g.to(gpu), images.to(gpu), ids.to(gpu), labels.to(gpu)
+    if not fused:       # the reference's step: cached encoder outputs in, head only (main_bigvul.py:308-345)
+        images = synth.tensor("abl/img", (8, 1024), -1, 1).to(gpu)
+        ids = synth.tensor("abl/txt", (8, 768), -1, 1).to(gpu)
+    losses = []
+    for _ in range(8):
+        loss, _ = cross_entropy(model(g, images, ids), labels)
+        loss.backward()
+        norm = opt.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
+    print(f"[{head} fused={fused}] losses", [round(x, 4) for x in losses])
+    assert min(losses[4:]) < losses[0] - 0.02
