@@ -98,3 +98,89 @@ def make_batch(indices, img_size=448, seq_len=512, vocab=51416, n_lo=150, n_hi=2
     ids = torch.stack([make_ids(i, seq_len, vocab, lo=tok_lo, salt=salt) for i in indices])
     labels = torch.tensor([make_label(i, salt) for i in indices], dtype=torch.int64)
     return g, images, ids, labels
+
+
+def make_joern_cpg(index: int, n_lines=40, salt=0):
+    """A synthetic Joern export of one function: (nodes_json, edges_json) in the layout ``svdj.get_node_edges`` reads
+    (sastvd/helpers/joern.py:260-275: node records with id / _label / name / code / lineNumber / controlStructureType, edge rows
+    [innode, outnode, etype, dataflow]).  It carries everything the reference's filters act on: META_DATA / FILE / COMMENT / <global>
+    records, nodes without a line number (TYPE, METHOD_RETURN), "<empty>" and empty code, several CPG nodes per source line, duplicate
+    line-level edges, CONTAINS / DOMINATE / POST_DOMINATE / SOURCE_FILE / REACHING_DEF / EVAL_TYPE / REF edges next to AST / CFG / CDG, lines
+    that only non-kept edge types touch.  Every edge leaves a node that has a line (see tests/golden/make_golden.py: the reference's own
+    TYPE-pseudo-node loop cannot run on pandas >= 2)."""
+    rng = np.random.default_rng(int(synth.name_seed(f"joern/{index}", salt)))
+    nodes, edges, nid = [], [], [1000]
+
+    def node(label, name="", code="", line=None, cst=None):
+        r = {"id": nid[0], "_label": label, "name": name, "code": code}
+        if line is not None:
+            r["lineNumber"] = int(line)
+        if cst is not None:
+            r["controlStructureType"] = cst
+        nodes.append(r)
+        nid[0] += int(rng.integers(1, 4))
+        return r["id"]
+
+    node("META_DATA", "", "<empty>")
+    node("FILE", "f.c", "<empty>")
+    node("NAMESPACE_BLOCK", "<global>", "<global>", 1)
+    types = [node("TYPE", t, "") for t in ("int", "char", "size_t")]
+    method = node("METHOD", f"fn{index}", f"int fn{index} (char *p, size_t n)", 1)
+    ret = node("METHOD_RETURN", "RET", "RET")
+    node("COMMENT", "", "/* c */", 2)
+    per_line = {}
+    for ln in range(2, n_lines + 2):
+        k = int(rng.integers(1, 5))
+        ids = []
+        for j in range(k):
+            kind = int(rng.integers(0, 5))
+            ident = "v" * int(rng.integers(1, 9)) + str(int(rng.integers(0, 99)))
+            if kind == 0:
+                ids.append(node("CALL", "<operator>.assignment", f"{ident} = {ident} + {j}", ln))
+            elif kind == 1:
+                ids.append(node("IDENTIFIER", ident, ident, ln))
+            elif kind == 2:
+                ids.append(node("LITERAL", str(j), "<empty>" if j % 2 else "", ln))
+            elif kind == 3:
+                ids.append(node("CONTROL_STRUCTURE", "", f"if ({ident} < n)", ln, "IF"))
+            else:
+                ids.append(node("LOCAL", ident, f"int {ident}", ln))
+        # a unique longest code per line: pandas picks a line's representative with an unstable sort, ties are not defined by the reference
+        used = set()
+        for r in nodes[-k:]:
+            eff = r["code"] if r["code"] not in ("", "<empty>") else r["name"]
+            while len(eff) in used:
+                eff += "_"
+            used.add(len(eff))
+            if r["code"] in ("", "<empty>"):
+                r["name"] = eff
+            else:
+                r["code"] = eff
+        per_line[ln] = ids
+    lines = sorted(per_line)
+
+    def edge(outn, inn, et, df=""):
+        edges.append([inn, outn, et, df])
+
+    for ln in lines:                                        # AST: method -> first node of a line -> the rest of the line
+        ids = per_line[ln]
+        if rng.random() < 0.85:
+            edge(method, ids[0], "AST")
+        for a in ids[1:]:
+            edge(ids[0], a, "AST")
+            edge(ids[0], a, "CONTAINS")
+    for a, b in zip(lines[:-1], lines[1:]):                 # CFG chain with some repeats (duplicate line-level edges) and skips
+        if rng.random() < 0.8:
+            edge(per_line[a][-1], per_line[b][0], "CFG")
+            if rng.random() < 0.3:
+                edge(per_line[a][0], per_line[b][-1], "CFG")
+        edge(per_line[a][0], per_line[b][0], "DOMINATE")
+        edge(per_line[b][0], per_line[a][0], "POST_DOMINATE")
+    for _ in range(n_lines):                                # CDG / REACHING_DEF / REF between random lines
+        a, b = (int(x) for x in rng.choice(lines, 2))
+        edge(per_line[a][0], per_line[b][-1], ("CDG", "REACHING_DEF", "REF")[int(rng.integers(0, 3))], "x")
+    for ln in lines[::3]:                                   # into nodes without a line: dropped by the line filters
+        edge(per_line[ln][0], types[int(rng.integers(0, 3))], "EVAL_TYPE")
+        edge(per_line[ln][-1], ret, "CFG")
+    edge(method, nodes[1]["id"], "SOURCE_FILE")
+    return nodes, edges

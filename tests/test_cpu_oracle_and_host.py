@@ -97,6 +97,63 @@ def test_oracle_ablation_heads_match_reference_golden(mod, sfx):
         assert float((lg - torch.from_numpy(gd[f"{name}/{mode}"])).abs().max()) < 2e-5, (name, mode)
 
 
+def _joern_cases():
+    import json
+    import os
+    from util import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "joern_cpg.json")))
+
+
+@pytest.mark.parametrize("case", ["1", "2", "3"])
+def test_joern_ingest_matches_reference_pipeline(case):
+    """SURVEY 8f row 2, host half: Joern's nodes / edges JSON -> line-level graph.  The expected values are what the REFERENCE's pandas
+    pipeline (svdj.get_node_edges -> ne_groupnodes -> rdg("all") -> drop_lone_nodes -> renumbering, data_list.py:343-376) returned for
+    these exports (tests/golden/make_golden.py gen_joern; inputs and outputs both committed).  Node order is descending code length
+    in both; the reference leaves the order among equal lengths to an unstable sort, so nodes are compared as {line: code} and edges
+    as (line_in, line_out, type) triples in file order."""
+    from mvuld_amd.data import joern_ingest as ji
+    c = _joern_cases()[case]
+    code, lineno, ei, eo, et = ji.feature_extraction(c["nodes"], c["edges"], "all")
+    assert dict(zip(lineno, code)) == dict(zip(c["lineno"], c["code"])) and len(set(lineno)) == len(lineno)
+    assert [len(x) for x in code] == [len(x) for x in c["code"]]
+    mine = [(lineno[a], lineno[b], t) for a, b, t in zip(ei, eo, et)]
+    assert mine == [(c["lineno"][a], c["lineno"][b], t) for a, b, t in zip(c["ei"], c["eo"], c["et"])]
+    # the generator that made the committed inputs still makes them (numpy Generator stream), so new cases can be added the same way
+    from mvuld_amd.data import synthetic
+    n2, e2 = synthetic.make_joern_cpg(int(case), {"1": 12, "2": 40, "3": 75}[case])
+    assert n2 == c["nodes"] and e2 == c["edges"]
+
+
+def test_joern_function_graph_layout(tmp_path):
+    """ImageList.item's graph (data_list.py:279-314): edges run out-node -> in-node, OCR boxes by line number (zeros when the line was
+    not recognised), one self-loop per node appended after the real edges with edge type 0; files are read as Joern names them."""
+    import json
+    from mvuld_amd.data import joern_ingest as ji
+    c = _joern_cases()["2"]
+    path = str(tmp_path / "7.c")
+    json.dump(c["nodes"], open(path + ".nodes.json", "w"))
+    json.dump(c["edges"], open(path + ".edges.json", "w"))
+    nodes_json, edges_json = ji.load_cpg(path)
+    boxes = {ln: [0.1, 0.2, 0.3 + 0.001 * ln, 0.4] for ln in c["lineno"][::2]}
+    g, code = ji.build_function_graph(nodes_json, edges_json, boxes)
+    n, e = len(c["lineno"]), len(c["ei"])
+    assert g.number_of_nodes() == n and g.num_edges() == e + n and len(code) == n
+    lineno = [int(x) for x in g.ndata["_lineno"].tolist()]
+    idx = {ln: k for k, ln in enumerate(lineno)}
+    ref_idx = {ln: k for k, ln in enumerate(c["lineno"])}
+    assert [(lineno[a], lineno[b]) for a, b in zip(g.src[:e].tolist(), g.dst[:e].tolist())] == \
+           [(c["lineno"][a], c["lineno"][b]) for a, b in zip(c["eo"], c["ei"])]
+    assert g.src[e:].tolist() == list(range(n)) and g.dst[e:].tolist() == list(range(n))
+    assert g.edata["_ETYPE"][:e].tolist() == c["et"] and g.edata["_ETYPE"][e:].abs().sum() == 0
+    for ln, k in idx.items():
+        want = boxes.get(ln, [0.0] * 4)
+        assert torch.allclose(g.ndata["pos_emb"][k], torch.tensor(want, dtype=torch.float32))
+    assert set(idx) == set(ref_idx)
+    # graph types of svdj.rdg: a sub-selection never has more edges, and "cfg" keeps only CFG edges
+    _, _, ei_c, _, et_c = ji.feature_extraction(nodes_json, edges_json, "cfg")
+    assert 0 < len(ei_c) < e and set(et_c) == {ji.ETYPE_MAP["CFG"]}
+
+
 def test_oracle_gat_softmax_properties():
     """edge softmax sums to one over the incoming edges of every destination, multi-edges counted separately."""
     from oracle import head_ref

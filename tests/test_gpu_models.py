@@ -1237,3 +1237,39 @@ def test_ablation_head_selected_by_config_trains(gpu, head, fused):
         assert math.isfinite(losses[-1]) and math.isfinite(float(norm))
     print(f"[{head} fused={fused}] losses", [round(x, 4) for x in losses])
     assert min(losses[4:]) < losses[0] - 0.02
+
+
+def test_joern_export_to_head_logits(gpu):
+    """SURVEY 8f row 2 end to end: three Joern CPG exports -> line-level graphs on the host (data/joern_ingest.py, pinned against the
+    reference's pandas pipeline by the CPU suite) -> batched, moved to the GPU, CSR index built there (graph_index.hip) -> the full head.
+    Logits equal the oracle's on the same edge lists (fp32), i.e. nothing between the JSON and the kernels reorders or drops an edge."""
+    import json
+    from oracle import head_ref
+    from mvuld_amd.data import joern_ingest as ji
+    from mvuld_amd.graph import batch
+    from mvuld_amd.models.GraphModel import Multi_DefectModel_new_GCN
+    from mvuld_amd import ops
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "joern_cpg.json")))
+    gs = []
+    for k in ("1", "2", "3"):
+        c = cases[k]
+        g, code = ji.build_function_graph(c["nodes"], c["edges"], {ln: [0.1, 0.2, 0.5, 0.9] for ln in c["lineno"][::3]})
+        n = g.number_of_nodes()
+        g.ndata["_UNIX_NODE_EMB"] = synth.tensor(f"joern/emb{k}", (n, 768), -0.5, 0.5)
+        gs.append(g)
+    g = batch(gs)
+    B = len(gs)
+    img, txt = synth.tensor("joern/img", (B, 1024), -1, 1), synth.tensor("joern/txt", (B, 768), -1, 1)
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_CLASSES=2))
+    m = Multi_DefectModel_new_GCN(cfg, act_dtype=torch.float32)
+    sd, _ = load_synth_into(m)
+    m = m.to(gpu).eval()
+    ops.bump_weight_epoch()
+    with torch.no_grad():
+        ref = head_ref.head_forward(sd, g.src, g.dst, g.batch_num_nodes(), g.ndata["_UNIX_NODE_EMB"], g.ndata["pos_emb"], img, txt)
+        gd = g.to(gpu)
+        lg = m(gd, img.to(gpu), txt.to(gpu)).float().cpu()
+    assert gd.src.is_cuda and gd._index is not None
+    err = float((lg - ref).abs().max())
+    print(f"[joern -> head] {g.number_of_nodes()} nodes, {g.num_edges()} edges, logits abs err {err:.2e}")
+    assert err < 1e-3
