@@ -82,6 +82,10 @@ int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
  * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */
 int mvuld_set_gemm_p256_rows(int rows);
+/* routing of mvuld_gemm_nt to the experimental deferred-epilogue 128 x 256 kernel (gemm_p128d.hip; measured slower than the 256-row
+ * kernel, see its header): 0 never (default), 1 rule (N >= 1536, K <= 1024, >= 2 tiles per CU), 2 whenever the shape is legal;
+ * initialised from MVULD_GEMM_P128D */
+int mvuld_set_gemm_p128d_mode(int mode);
 
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
  * layout, fp32 accumulate); dbias[N] += column sums of dY when non-null.  The token contraction is split over workgroups.

@@ -169,6 +169,48 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(6401, 2056, 544), (20000, 1288, 160), (70000, 512, 128), (769, 520, 1024), (25088, 2048, 512), (300, 2048, 256),
+                                   (16384, 3072, 768), (12800, 1536, 224)])
+def test_gemm_p128d_deferred_epilogue(gpu, M, N, K):
+    """The 128 x 256-tile kernel whose epilogue runs under the next tile's main loop (csrc/gemm_p128d.hip), forced on ragged and on the
+    step's own shapes: one or many tiles per workgroup (a lone tile is all flush), 4 to 32 ring steps (two epilogue chunks per k-step
+    below 8 steps), M / N tails (edge waves do not count their predicated stores in the run-time vmcnt), NONE / BIAS / GELU (+ stored
+    pre-activation).  Against the fp32 product of the bf16-rounded operands and, for structure, the older kernels' bf16 matrix; repeated
+    launches must agree bit for bit (a mis-counted wait reads an LDS stage before its DMA has landed: it shows as run-to-run differences)."""
+    from mvuld_amd import ops, hip
+    g = torch.Generator().manual_seed(13)
+    a = (torch.rand((M, K), generator=g) - 0.5).to(torch.bfloat16)
+    b = (torch.rand((N, K), generator=g) - 0.5).to(torch.bfloat16)
+    bias = torch.rand((N,), generator=g) - 0.5
+    A, B_, Bi = a.to(gpu), b.to(gpu), bias.to(gpu)
+    ref = (A.float() @ B_.float().t()).cpu()
+    hip.LIB.fn("mvuld_set_gemm_p256_mode")(2)
+    hip.LIB.fn("mvuld_set_gemm_p128d_mode")(2)
+    try:
+        out = ops.gemm_nt(A, B_)
+        assert rel(out, ref) < 1e-2
+        hip.LIB.fn("mvuld_set_gemm_p128d_mode")(0)
+        hip.LIB.fn("mvuld_set_gemm_p256_mode")(0)
+        old = ops.gemm_nt(A, B_)
+        hip.LIB.fn("mvuld_set_gemm_p256_mode")(2)
+        hip.LIB.fn("mvuld_set_gemm_p128d_mode")(2)
+        assert float((out.float() - old.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+        out = ops.gemm_nt(A, B_, bias=Bi)
+        assert rel(out, ref + bias) < 1e-2
+        aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
+        out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=aux)
+        assert rel(aux, ref + bias) < 1e-2 and rel(out, F.gelu(ref + bias)) < 1e-2
+        out2 = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU)
+        assert torch.equal(out2, out)
+        for _ in range(6):
+            aux2 = torch.empty_like(aux)
+            again = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=aux2)
+            assert torch.equal(again, out) and torch.equal(aux2, aux)
+    finally:
+        hip.LIB.fn("mvuld_set_gemm_p256_mode")(1)
+        hip.LIB.fn("mvuld_set_gemm_p128d_mode")(0)
+
+
 def _e4m3_deq(q):
     return q.cpu().view(torch.float8_e4m3fn).float()
 
