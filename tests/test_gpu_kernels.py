@@ -211,6 +211,28 @@ def test_gemm_p128d_deferred_epilogue(gpu, M, N, K):
         hip.LIB.fn("mvuld_set_gemm_p128d_mode")(0)
 
 
+@pytest.mark.parametrize("dtype,C", [(torch.bfloat16, 768), (torch.bfloat16, 520), (torch.bfloat16, 100), (torch.float32, 768)])
+def test_segment_mean_ragged(gpu, dtype, C):
+    """Sentence vector over packed rows / dgl.mean_nodes: per-segment mean of ragged row runs (lengths 1 .. 512), the 16-byte row-parallel
+    kernel (bf16, C % 8 == 0) and the scalar one, forward and backward, against torch."""
+    from mvuld_amd.hip import call, ptr, dt
+    lens = [1, 512, 7, 130, 64, 9, 300, 2]
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    T, B = int(off[-1]), len(lens)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand((T, C), generator=g) - 0.5).to(dtype)
+    X, O = x.to(gpu), off.to(gpu)
+    out = torch.empty((B, C), dtype=dtype, device=gpu)
+    call("segment_mean_fwd", ptr(X), ptr(O), ptr(out), B, C, dt(X))
+    ref = torch.stack([x[off[b]:off[b + 1]].float().mean(0) for b in range(B)])
+    assert float((out.float().cpu() - ref).abs().max()) < (1e-6 if dtype == torch.float32 else 2.5e-3)
+    dout = (torch.rand((B, C), generator=g) - 0.5).to(dtype)
+    dx = torch.empty((T, C), dtype=dtype, device=gpu)
+    call("segment_mean_bwd", ptr(dout.to(gpu)), ptr(O), ptr(dx), B, C, dt(dx))
+    refd = torch.cat([(dout[b].float() / lens[b]).expand(lens[b], C) for b in range(B)])
+    assert float((dx.float().cpu() - refd).abs().max()) < (1e-6 if dtype == torch.float32 else 2.5e-3)
+
+
 def _e4m3_deq(q):
     return q.cpu().view(torch.float8_e4m3fn).float()
 
