@@ -47,12 +47,18 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // geometry is unchanged; a lane's 16-byte chunk feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (its low and high 8 bytes: the same k subset
 // on both operands, so any split is a valid contraction order).  Half the L2 -> LDS bytes and LDS reads per FLOP.
 typedef long __attribute__((ext_vector_type(2))) i64x2_t;
-template <int EPI, int NI, bool FP8 = false>
+// NS = ring stages: 4 (32 KiB stages at any NI) or 5 (NI <= 7: stages of (2 NI + 16) KiB, 152 KiB at NI = 7) -- one more k-step between an
+// epilogue's burst of stores and the first operand load that has to wait for them (vmcnt retires in issue order).
+template <int EPI, int NI, bool FP8 = false, int NS = 4>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* glb_vp;
     constexpr int BM = 32 * NI, WM = 16 * NI;           // tile rows, rows per wave
+    constexpr int A_BYTES = NS == 4 ? 16384 : 2 * NI * 1024;                 // A region of a stage (B follows: 16 KiB)
+    constexpr int STAGE = A_BYTES + 16384;
+    constexpr int BIAS_OFF = NS * STAGE;
+    static_assert(NS == 4 || (NS == 5 && NI <= 7), "five stages only fit below 256 rows");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // 2 x 4 waves, WM (m) x 64 (n) each
@@ -98,17 +104,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         // vmcnt(0)); older than the tile's first operand stage, so the wait that retires that stage retires it too
         if (g.bias && wave == 0) {
             const int c = n0 + 4 * lane;
-            __builtin_amdgcn_global_load_lds((glb_vp)(g.bias + (c < g.N ? c : 0)), (lds_vp)(smem + P_BIAS_OFF + (ord & 1) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(g.bias + (c < g.N ? c : 0)), (lds_vp)(smem + BIAS_OFF + (ord & 1) * 1024), 16, 0, 0);
         }
     };
     auto issue_one = [&]() {
         if (issued < total) {
-            char* st = smem + (issued & 3) * P_STAGE_BYTES;
+            char* st = smem + (issued % NS) * STAGE;
             const int k0 = iss_kt * 64;                  // bytes
             __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + wave * 1024), 16, 0, 0);
             if (a2) __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave + 8) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + 16384 + (wave * 2) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(gb[1] + k0), (lds_vp)(st + 16384 + (wave * 2 + 1) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + A_BYTES + (wave * 2) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gb[1] + k0), (lds_vp)(st + A_BYTES + (wave * 2 + 1) * 1024), 16, 0, 0);
             ++issued;
             if (++iss_kt == nk) {
                 iss_kt = 0;
@@ -117,16 +123,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         }
     };
     if (my_tiles > 0) setup_ptrs(0);
-    issue_one();
-    issue_one();
-    issue_one();
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue_one();
 
     // fragment byte offsets inside a stage: weights (MFMA A port) 4 x 16 columns, activations (B port) NI x 16 rows
     int oa[NI], ob[4];
 #pragma unroll
     for (int i = 0; i < NI; ++i) oa[i] = p_off(wr * WM + i * 16 + fr, fg);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = 16384 + p_off(wc * 64 + j * 16 + fr, fg);
+    for (int j = 0; j < 4; ++j) ob[j] = A_BYTES + p_off(wc * 64 + j * 16 + fr, fg);
 
     // stores one epilogue leaves in flight (known exactly only for a wave whose sub-tile is interior: every store executes)
     constexpr int ST1 = 2 * NI, ST2 = 4 * NI, ST3 = 6 * NI;
@@ -146,20 +151,23 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             // step cs's loads and now -- counting them lets the stores drain under the MFMAs instead of in front of them.  vmcnt
             // retires in issue order, so from the fourth step on the stores are older than the awaited loads and must be complete.
             const int younger = total - 1 - cs;
-            if (younger >= 2) {
-                if (kt < 3 && pend == ST1) { if (a2) wait_vm<8 + ST1>(); else wait_vm<6 + ST1>(); }
-                else if (kt < 3 && pend == ST2) { if (a2) wait_vm<8 + ST2>(); else wait_vm<6 + ST2>(); }
-                else if (FP8 && kt < 3 && pend == ST3) { if (a2) wait_vm<8 + ST3>(); else wait_vm<6 + ST3>(); }
-                else if (a2) wait_vm<8>();
-                else wait_vm<6>();
+            constexpr int AH = NS - 2;                   // k-steps allowed to stay in flight behind the awaited one
+            if (younger >= AH) {
+                if (kt < NS - 1 && pend == ST1) { if (a2) wait_vm<4 * AH + ST1>(); else wait_vm<3 * AH + ST1>(); }
+                else if (kt < NS - 1 && pend == ST2) { if (a2) wait_vm<4 * AH + ST2>(); else wait_vm<3 * AH + ST2>(); }
+                else if (FP8 && kt < NS - 1 && pend == ST3) { if (a2) wait_vm<4 * AH + ST3>(); else wait_vm<3 * AH + ST3>(); }
+                else if (a2) wait_vm<4 * AH>();
+                else wait_vm<3 * AH>();
+            } else if (younger == 2) {                   // NS == 5 only
+                if (a2) wait_vm<8>(); else wait_vm<6>();
             } else if (younger == 1) {
                 if (a2) wait_vm<4>(); else wait_vm<3>();
             } else {
                 wait_vm<0>();
             }
             __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done with step cs - 1
-            issue_one();                                 // step cs + 3 refills the stage step cs - 1 occupied
-            const char* st = smem + (cs & 3) * P_STAGE_BYTES;
+            issue_one();                                 // step cs + NS - 1 refills the stage step cs - 1 occupied
+            const char* st = smem + (cs % NS) * STAGE;
             constexpr int H0 = (NI + 1) / 2;
             // the second half of the activation fragments is read UNDER the first half's MFMAs
             if constexpr (!FP8) {
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         float b4[4][4];
         if (g.bias) {
             // inline asm: a ds_read hipcc can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0) in front of every read)
-            const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + P_BIAS_OFF + (ord & 1) * 1024 + (wc * 64 + 4 * fg) * 4);
+            const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + BIAS_OFF + (ord & 1) * 1024 + (wc * 64 + 4 * fg) * 4);
             f32x4_t t0, t1, t2, t3;
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                          "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
@@ -333,16 +341,34 @@ static int p256_num_cus() {
     return n;
 }
 
+// MVULD_P256_STAGES = 4 (default) | 5 (tiles below 256 rows only).  Measured: five stages make the isolated products 1.2 % faster
+// (19.55 vs 19.78 ms per step's worth) and the whole multi-stream step 0.3 % slower (60.5 vs 60.3 ms, two runs each): kept as a switch.
+static int p256_stages() {
+    static const int n = [] { const char* e = getenv("MVULD_P256_STAGES"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
+    return n;
+}
 template <int EPI, int NI>
 static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
+    const int tiles_m = (int)cdiv(g.M, 32 * NI);
+    const int nt = tiles_m * tiles_n;
+    const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    if constexpr (NI <= 7) {
+        if (p256_stages() == 5) {
+            constexpr int LDS5 = 5 * (2 * NI * 1024 + 16384) + 2048;
+            static const bool attr5 = [] {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
+                return true;
+            }();
+            (void)attr5;
+            hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 5>), dim3(grid), dim3(512), LDS5, stream, g, tiles_m, tiles_n);
+            return;
+        }
+    }
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
         return true;
     }();
     (void)attr;
-    const int tiles_m = (int)cdiv(g.M, 32 * NI);
-    const int nt = tiles_m * tiles_n;
-    const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
     hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
 }
 
