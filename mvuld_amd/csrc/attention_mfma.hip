@@ -50,7 +50,7 @@ typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
 typedef bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
 __device__ __forceinline__ unsigned am_pk(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
 #ifndef AM_X
-#define AM_X 0      // timing experiments (tools/attn_variants.sh): 1 = no exp, 2 = no bias reads, 3 = no transposed reads
+#define AM_X 0      // timing experiments (tools/attn_variants.sh): 1 = no exp, 2 = no bias reads, 3 = no transposed reads; bias-table pass: 4 = K/V fragments read once per item, 5 = q-side rows fetched once per item
 #endif
 __device__ __forceinline__ f32x2_t am_exp2(f32x2_t v) {
 #if AM_X == 1
@@ -794,7 +794,11 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
         QRow cur, nxt;
         fetch(0, cur);
         for (int yq = 0; yq < ws; ++yq) {
+#if AM_X == 5
+            if (yq == 0) fetch(1, nxt);
+#else
             fetch(min(yq + 1, ws - 1), nxt);
+#endif
             // a dy switches from its complement (dy - ws) to itself when the sweep reaches image row dy
 #pragma unroll
             for (int j = 0; j < G; ++j) {
@@ -815,10 +819,16 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
                 fk0[slot] = *(const bf16x8_t*)(Ks + ko + kb0); fk1[slot] = *(const bf16x8_t*)(Ks + ko + kb1);
                 fv0[slot] = *(const bf16x8_t*)(Vs + ko + kb0); fv1[slot] = *(const bf16x8_t*)(Vs + ko + kb1);
             };
+#if AM_X == 4
+            if (yq == 0) { frags(0, 0); frags(1, 1); }
+#else
             frags(0, 0);
+#endif
 #pragma unroll
             for (int j = 0; j < G; ++j) {
+#if AM_X != 4
                 if (j + 1 < G) frags(j + 1, (j + 1) & 1);                  // next tile's LDS reads fly under this tile's math
+#endif
                 const int dyc = min(grp * G + j, ws - 1);
                 const int yk = yq - dyc + (yq < dyc ? ws : 0);
                 const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yk) != rq;
