@@ -157,6 +157,10 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
  * the backward passes from the same seed.  p = 0 switches it off. */
 /* mode 2 (matrix-core kernels only): mode 1 over PACKED sequences: `valid` carries cu [B+1], N = the longest sequence allowed
  * (sizes LDS and the lse rows: lse is [B, H, N]), `res` = total packed tokens; every packed token is a valid key. */
+/* forward / dQ / dK,dV passes: when the (window x head) groups do not fill whole rounds of the CUs (the text encoder's 32 x 12 = 384
+ * on 256), the groups of the partial last round are split over 2..4 workgroups each so that it fills up (results are bit-identical:
+ * a query / key tile is computed by one wave either way).  1 = on, 0 = off (default; MVULD_ATTN_TAIL_SPLIT) -- measured neutral */
+int mvuld_set_attn_tail_split(int on);
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
  * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).

@@ -567,6 +567,49 @@ def test_padmask_attention(gpu, dtype, impl, hd, L):
     assert rel(dqkv.float().cpu() * vm, q_.grad * vm) < tol(dtype) * 2
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_attention_tail_balanced_launch_is_bit_identical(gpu, mode):
+    """384 (window x head) groups on 256 CUs: the launch plan gives the first 256 a workgroup each and splits the last 128 in two
+    (attention_mfma.hip am_plan).  A query / key tile is still computed by exactly one wave, so outputs, lse, dQ / dK / dV must equal the
+    unsplit launch bit for bit -- Swin geometry (shifted 28-windows, 6 images x 4 windows x 16 heads) and the text encoder's
+    (32 x 12 heads x 512 tokens, ragged lengths)."""
+    from mvuld_amd import ops, hip
+    if mode == 0:
+        B, H, hd, res, ws, shift = 6, 16, 32, 56, 28, 14
+        g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+        tokens, C = B * res * res, H * hd
+        table, ls, valid = dev(T("tb", ((2 * ws - 1) ** 2, H), 0.0, 16.0)), dev(T("tls", (H,), 1.5, 3.0)), None
+    else:
+        B, H, hd, L = 32, 12, 64, 512
+        g = ops.AttnGeom(1, B, H, hd, L, 1, 0, 0, 0, 1.0 / math.sqrt(hd))
+        tokens, C = B * L, H * hd
+        v = torch.zeros(B, L, dtype=torch.int32)
+        for i in range(B):
+            v[i, :L - 13 * i] = 1
+        table = ls = None
+        valid = dev(v)
+    assert B * g.nW * H == 384
+    qkv = dev(T("tq", (tokens, 3 * C), -2, 2), torch.bfloat16)
+    dout = dev(T("tdo", (tokens, C)), torch.bfloat16)
+    res_ = []
+    try:
+        for on in (0, 1):
+            hip.LIB.fn("mvuld_set_attn_tail_split")(on)
+            out, lse = ops.attn_fwd(g, qkv, table, ls, valid)
+            dtab = torch.zeros_like(table) if mode == 0 else None
+            dls = torch.zeros(H, device=gpu) if mode == 0 else None
+            dqkv = ops.attn_bwd(g, qkv, out, dout, lse, table, ls, valid, dtab, dls)
+            torch.cuda.synchronize()
+            res_.append((out.clone(), lse.clone(), dqkv.clone(), dtab))
+    finally:
+        hip.LIB.fn("mvuld_set_attn_tail_split")(0)
+    (o0, l0, d0, t0), (o1, l1, d1, t1) = res_
+    assert torch.isfinite(o0.float()).all() and float(o0.float().abs().max()) > 0
+    assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(d0, d1)
+    if mode == 0:
+        assert rel(t1, t0) < 1e-5           # float atomics order
+
+
 def test_cpb_table(gpu):
     from mvuld_amd import hip
     from mvuld_amd.hip import call, ptr
