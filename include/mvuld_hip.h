@@ -82,6 +82,14 @@ int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
  * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */
 int mvuld_set_gemm_p256_rows(int rows);
+/* Schedule of that kernel's main loop: 1 (default) = ping-pong -- the two waves of every SIMD run half a k-step apart, one reading its
+ * fragments from LDS while the other owns the matrix pipe; 0 = both in lockstep (one barrier per k-step).  Bit-identical results;
+ * initialised from MVULD_P256_PINGPONG (A/B timing, tests). */
+int mvuld_set_gemm_p256_pingpong(int on);
+/* Ring geometry of that kernel for bf16 products with K % 64 == 0: 1 = 64-deep stages fetched as full 128-byte lines (8 rows x 128 bytes
+ * per LDS-DMA instruction; 2 stages, 3 at <= 160-row tiles), 0 = 32-deep stages (16 rows x 64 bytes per instruction, 4 stages).
+ * Bit-identical results; initialised from MVULD_P256_K64. */
+int mvuld_set_gemm_p256_k64(int on);
 /* routing of mvuld_gemm_nt to the experimental deferred-epilogue 128 x 256 kernel (gemm_p128d.hip; measured slower than the 256-row
  * kernel, see its header): 0 never (default), 1 rule (N >= 1536, K <= 1024, >= 2 tiles per CU), 2 whenever the shape is legal;
  * initialised from MVULD_GEMM_P128D */

@@ -23,6 +23,9 @@
 #define P256_X 0      // timing experiments (tools/p256_variants.sh): bit 0 = epilogue without its stores, bit 1 = without GELU / dGELU math
 #endif
 #define P_BK 32
+#ifndef P256_K64_DEFAULT
+#define P256_K64_DEFAULT 0
+#endif
 #define P_STAGE_BYTES 32768
 #define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
 #define P_LDS_BYTES (4 * P_STAGE_BYTES + 2048)
@@ -30,6 +33,11 @@
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [256][32] bf16 tile (64-byte rows): slot XORed with the row group so
 // that every 16-lane group of a ds_read_b128 fragment read covers all 64 banks (same image as gemm.hip's ring kernels)
 __device__ __forceinline__ int p_off(int row, int ch) { return row * 64 + ((ch ^ ((4 - ((row >> 2) & 3)) & 3)) << 4); }
+
+// the same for a [rows][64] bf16 tile (128-byte rows, chunks 0..7): chunk ^ ((row >> 1) & 7).  A ds_read_b128 is served in groups of
+// 16 lanes = rows {0-3, 12-15} of chunk c and rows {4-11} of chunk c + 1 (or the complement): even rows take slots 0..7 of the 256-byte
+// bank line, odd rows 8..15, and (c ^ {0, 1, 6, 7}) with ((c + 1) ^ {2, 3, 4, 5}) are eight different slots for every c.
+__device__ __forceinline__ int p_off128(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     typedef bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
@@ -49,16 +57,35 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 typedef long __attribute__((ext_vector_type(2))) i64x2_t;
 // NS = ring stages: 4 (32 KiB stages at any NI) or 5 (NI <= 7: stages of (2 NI + 16) KiB, 152 KiB at NI = 7) -- one more k-step between an
 // epilogue's burst of stores and the first operand load that has to wait for them (vmcnt retires in issue order).
-template <int EPI, int NI, bool FP8 = false, int NS = 4>
+// PP = ping-pong schedule of the two wave rows.  Waves w and w + 4 (wr = 0 / 1, same wc) share a SIMD.  With one barrier per k-step both
+// reach the 12 fragment reads together and then the 32 MFMAs together: the matrix pipe idles through every read phase (the compiled loop
+// is barrier, DMA issue, 12 ds_read_b128, lgkmcnt(0), 32 MFMAs: ~0.75 us per step against 0.43 us of MFMA time).  PP splits a k-step
+// into two barrier epochs and runs row 1 one epoch behind row 0, so one wave of every SIMD reads its fragments (and issues its share of
+// the DMA) while the other one owns the matrix pipe.  Same registers, same ring, same vmcnt accounting: every wave still issues one
+// k-step of DMA per k-step, right after the barrier that opens its read epoch, and step c has been awaited by EVERY wave before the
+// barrier that opens row 0's read epoch of c (row 0 waits in front of it as before, row 1 waits for c at the end of its read epoch of
+// c - 1, which closes with that same barrier).  A tile's epilogue is not staggered: row 1 takes one barrier alone in front of the k-loop,
+// row 0 one behind it, so both rows meet again at the epilogue (bias slices, store accounting and the tile walk are unchanged).
+// K64 = 64-deep ring stages fetched as FULL 128-byte lines (bf16, PP only).  A 32-deep stage takes 64 bytes of every operand row per k-step:
+// half a cache line per request, every line requested twice from L2 -- the L2 -> LDS path then tops out near 11 TB/s chip-wide (0.75 us per
+// 32-deep step of a 256 x 256 tile, whatever the schedule of the waves: the ping-pong loop gained 3 %).  Here a DMA instruction fills
+// 8 rows x 128 bytes (lane l -> row l >> 3, slot l & 7, source chunk = slot ^ ((row >> 1) & 7): every 16-lane group of a ds_read_b128 fragment
+// read still covers all 64 banks), a stage is (32 NI + 256) rows x 128 bytes and is consumed as two 32-deep sub-steps (the second one's
+// chunk index is the first one's ^ 4: byte offset ^ 64), so the contraction order -- and every output bit -- is that of the 32-deep ring.
+// Stages: 2 at NI >= 6 (2 x 64 KiB at NI = 8), 3 at NI <= 5 (3 x 52 KiB at NI = 5).
+template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* glb_vp;
     constexpr int BM = 32 * NI, WM = 16 * NI;           // tile rows, rows per wave
-    constexpr int A_BYTES = NS == 4 ? 16384 : 2 * NI * 1024;                 // A region of a stage (B follows: 16 KiB)
-    constexpr int STAGE = A_BYTES + 16384;
+    constexpr int RB = K64 ? 128 : 64;                  // bytes of every operand row in a stage
+    constexpr int A_BYTES = K64 ? NI * 4096 : (NS == 4 ? 16384 : 2 * NI * 1024);      // A region of a stage (B follows: 256 rows)
+    constexpr int STAGE = A_BYTES + 256 * RB;
     constexpr int BIAS_OFF = NS * STAGE;
-    static_assert(NS == 4 || (NS == 5 && NI <= 7), "five stages only fit below 256 rows");
+    static_assert(K64 || NS == 4 || (NS == 5 && NI <= 7), "five stages only fit below 256 rows");
+    static_assert(!K64 || (PP && !FP8 && (NS == 2 || (NS == 3 && NI <= 5))), "64-deep stages: bf16, ping-pong, 2 stages (3 at <= 160 rows)");
+    static_assert(NS * STAGE + 2048 <= 163840, "ring does not fit the LDS");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // 2 x 4 waves, WM (m) x 64 (n) each
@@ -66,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     const int nt = tiles_m * tiles_n;
     const int G = gridDim.x, bx = blockIdx.x;
     constexpr int ES = FP8 ? 1 : 2;                      // bytes per operand element; a k-step is always 64 bytes of every row
-    const int nk = g.K * ES / 64;
+    const int nk = g.K * ES / RB;
     const int my_tiles = bx < nt ? (nt - bx + G - 1) / G : 0;
     const int total = my_tiles * nk;
     const char* A = (const char*)g.A;
@@ -86,19 +113,38 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     // one instruction fills 1 KiB = 16 tile rows in lane order (lane l -> row l >> 2, slot l & 3): the lane fetches the chunk the
     // swizzle keeps in its slot.  The A tile is 2 * NI pieces: wave w issues piece w and, if it exists, piece w + 8; the B tile is
     // 16 pieces: wave w issues pieces 2w, 2w + 1.  So a wave has 3 or 4 operations per k-step in flight (the counted waits below).
-    const bool a2 = wave + 8 < 2 * NI;                   // wave-uniform
-    const char* ga[2];
-    const char* gb[2];
+    // K64: the A tile is 4 * NI pieces of 8 rows: wave w issues pieces w, w + 8, ... (ALO or ALO + 1 of them); the B tile is 32 pieces:
+    // wave w issues pieces 4w .. 4w + 3.
+    constexpr int ALO = (4 * NI) / 8, AHI = (4 * NI + 7) / 8;
+    const bool a2 = K64 ? (wave + 8 * ALO < 4 * NI) : (wave + 8 < 2 * NI);        // wave-uniform: this wave issues the extra A piece
+    constexpr int OPS_LO = K64 ? ALO + 4 : 3, OPS_HI = K64 ? ALO + 5 : 4;          // DMA operations per k-step of a wave without / with it
+    constexpr int NPA = K64 ? AHI : 2, NPB = K64 ? 4 : 2;
+    const char* ga[K64 ? 1 : 2];
+    const char* gb[K64 ? 1 : 2];
+    unsigned fa_off[NPA], fb_off[NPB];                   // K64: 32-bit byte offsets from A / B (the host checks that they fit)
     int iss_ord = 0, iss_kt = 0, issued = 0;
     auto setup_ptrs = [&](int ord) {
         int m0, n0;
         tile_of(ord, m0, n0);
+        if constexpr (K64) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rowa = (wave + 8 * i) * 16 + (lane >> 2);
-            const int rowb = (wave * 2 + i) * 16 + (lane >> 2);
-            ga[i] = A + (int64_t)min(m0 + rowa, g.M - 1) * g.lda * ES + ((lane & 3) ^ ((4 - ((rowa >> 2) & 3)) & 3)) * 16;
-            gb[i] = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb * ES + ((lane & 3) ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 16;
+            for (int i = 0; i < NPA; ++i) {
+                const int rowa = (wave + 8 * i) * 8 + (lane >> 3);
+                fa_off[i] = (unsigned)min(m0 + rowa, g.M - 1) * (unsigned)(g.lda * ES) + ((lane & 7) ^ ((rowa >> 1) & 7)) * 16;
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int rowb = (wave * 4 + i) * 8 + (lane >> 3);
+                fb_off[i] = (unsigned)min(n0 + rowb, g.N - 1) * (unsigned)(g.ldb * ES) + ((lane & 7) ^ ((rowb >> 1) & 7)) * 16;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rowa = (wave + 8 * i) * 16 + (lane >> 2);
+                const int rowb = (wave * 2 + i) * 16 + (lane >> 2);
+                ga[i] = A + (int64_t)min(m0 + rowa, g.M - 1) * g.lda * ES + ((lane & 3) ^ ((4 - ((rowa >> 2) & 3)) & 3)) * 16;
+                gb[i] = B + (int64_t)min(n0 + rowb, g.N - 1) * g.ldb * ES + ((lane & 3) ^ ((4 - ((rowb >> 2) & 3)) & 3)) * 16;
+            }
         }
         // the tile's 256 bias columns ride the same DMA queue (a VGPR load in the epilogue would make hipcc drain it with
         // vmcnt(0)); older than the tile's first operand stage, so the wait that retires that stage retires it too
@@ -110,11 +156,22 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     auto issue_one = [&]() {
         if (issued < total) {
             char* st = smem + (issued % NS) * STAGE;
-            const int k0 = iss_kt * 64;                  // bytes
-            __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + wave * 1024), 16, 0, 0);
-            if (a2) __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave + 8) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + A_BYTES + (wave * 2) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(gb[1] + k0), (lds_vp)(st + A_BYTES + (wave * 2 + 1) * 1024), 16, 0, 0);
+            const int k0 = iss_kt * RB;                  // bytes
+            if constexpr (K64) {
+                const char* Ak = A + k0;                 // scalar bases: the loads take the  saddr + 32-bit voffset  form
+                const char* Bk = B + k0;
+#pragma unroll
+                for (int i = 0; i < NPA; ++i)
+                    if (i < ALO || a2) __builtin_amdgcn_global_load_lds((glb_vp)(Ak + fa_off[i]), (lds_vp)(st + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NPB; ++i)
+                    __builtin_amdgcn_global_load_lds((glb_vp)(Bk + fb_off[i]), (lds_vp)(st + A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((glb_vp)(ga[0] + k0), (lds_vp)(st + wave * 1024), 16, 0, 0);
+                if (a2) __builtin_amdgcn_global_load_lds((glb_vp)(ga[1] + k0), (lds_vp)(st + (wave + 8) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vp)(gb[0] + k0), (lds_vp)(st + A_BYTES + (wave * 2) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vp)(gb[1] + k0), (lds_vp)(st + A_BYTES + (wave * 2 + 1) * 1024), 16, 0, 0);
+            }
             ++issued;
             if (++iss_kt == nk) {
                 iss_kt = 0;
@@ -129,9 +186,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     // fragment byte offsets inside a stage: weights (MFMA A port) 4 x 16 columns, activations (B port) NI x 16 rows
     int oa[NI], ob[4];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) oa[i] = p_off(wr * WM + i * 16 + fr, fg);
+    for (int i = 0; i < NI; ++i) oa[i] = K64 ? p_off128(wr * WM + i * 16 + fr, fg) : p_off(wr * WM + i * 16 + fr, fg);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = A_BYTES + p_off(wc * 64 + j * 16 + fr, fg);
+    for (int j = 0; j < 4; ++j) ob[j] = A_BYTES + (K64 ? p_off128(wc * 64 + j * 16 + fr, fg) : p_off(wc * 64 + j * 16 + fr, fg));
 
     // stores one epilogue leaves in flight (known exactly only for a wave whose sub-tile is interior: every store executes)
     constexpr int ST1 = 2 * NI, ST2 = 4 * NI, ST3 = 6 * NI;
@@ -139,37 +196,86 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     const bool QE = FP8 && EPI == EPI_GELU && g.q_out != nullptr;      // workgroup-uniform
     float amax_l = 0.f;
     int cs = 0;                                          // compute step, counted across tiles (ring stage = cs & 3)
+    // Step xcs (k-step xkt of its tile) has landed once at most the operations issued after it are still in flight: normally the two
+    // younger k-steps (3 or 4 loads each); in the first three steps after an epilogue also that epilogue's stores, which were issued
+    // between step xcs's loads and now -- counting them lets the stores drain under the MFMAs instead of in front of them.  vmcnt
+    // retires in issue order, so from the fourth step on the stores are older than the awaited loads and must be complete.
+    // Precondition (both schedules): this wave has issued the DMA up to step xcs + NS - 2 and nothing younger.
+    auto wait_step = [&](int xkt, int xcs) {
+        const int younger = total - 1 - xcs;
+        constexpr int AH = NS - 2;                       // k-steps allowed to stay in flight behind the awaited one
+        if (younger >= AH) {
+            if (xkt < NS - 1 && pend == ST1) { if (a2) wait_vm<OPS_HI * AH + ST1>(); else wait_vm<OPS_LO * AH + ST1>(); }
+            else if (xkt < NS - 1 && pend == ST2) { if (a2) wait_vm<OPS_HI * AH + ST2>(); else wait_vm<OPS_LO * AH + ST2>(); }
+            else if (FP8 && xkt < NS - 1 && pend == ST3) { if (a2) wait_vm<OPS_HI * AH + ST3>(); else wait_vm<OPS_LO * AH + ST3>(); }
+            else if (a2) wait_vm<OPS_HI * AH>();
+            else wait_vm<OPS_LO * AH>();
+        } else if (younger == 2) {                       // NS == 5 only
+            if (a2) wait_vm<2 * OPS_HI>(); else wait_vm<2 * OPS_LO>();
+        } else if (younger == 1) {
+            if (a2) wait_vm<OPS_HI>(); else wait_vm<OPS_LO>();
+        } else {
+            wait_vm<0>();
+        }
+    };
     for (int ord = 0; ord < my_tiles; ++ord) {
         f32x4_t acc[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (K64) {
+            // opaque zeros: folded into the first MFMAs (C = 0) the peeled first k-step accumulates out of place, and its two MFMA
+            // blocks then hold two accumulator sets: 256 registers and spills whose reloads drain the DMA queue (vmcnt(0))
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        }
+        if (PP && wr == 1) {                             // row 1 falls one barrier epoch behind row 0
+            wait_step(0, cs);
+            __builtin_amdgcn_s_barrier();
+        }
         for (int kt = 0; kt < nk; ++kt, ++cs) {
-            // Step cs has landed once at most the operations issued after it are still in flight: normally the two younger k-steps
-            // (3 or 4 loads each); in the first three steps after an epilogue also that epilogue's stores, which were issued between
-            // step cs's loads and now -- counting them lets the stores drain under the MFMAs instead of in front of them.  vmcnt
-            // retires in issue order, so from the fourth step on the stores are older than the awaited loads and must be complete.
-            const int younger = total - 1 - cs;
-            constexpr int AH = NS - 2;                   // k-steps allowed to stay in flight behind the awaited one
-            if (younger >= AH) {
-                if (kt < NS - 1 && pend == ST1) { if (a2) wait_vm<4 * AH + ST1>(); else wait_vm<3 * AH + ST1>(); }
-                else if (kt < NS - 1 && pend == ST2) { if (a2) wait_vm<4 * AH + ST2>(); else wait_vm<3 * AH + ST2>(); }
-                else if (FP8 && kt < NS - 1 && pend == ST3) { if (a2) wait_vm<4 * AH + ST3>(); else wait_vm<3 * AH + ST3>(); }
-                else if (a2) wait_vm<4 * AH>();
-                else wait_vm<3 * AH>();
-            } else if (younger == 2) {                   // NS == 5 only
-                if (a2) wait_vm<8>(); else wait_vm<6>();
-            } else if (younger == 1) {
-                if (a2) wait_vm<4>(); else wait_vm<3>();
-            } else {
-                wait_vm<0>();
-            }
-            __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done with step cs - 1
+            if (!PP || wr == 0) wait_step(kt, cs);
+            __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done reading step cs - 1
             issue_one();                                 // step cs + NS - 1 refills the stage step cs - 1 occupied
             const char* st = smem + (cs % NS) * STAGE;
+            if constexpr (K64) {
+                // two 32-deep sub-steps, each a read epoch and a matrix epoch; row 1 runs one epoch behind row 0
+                bf16x8_t fa[NI], fb[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1) __builtin_amdgcn_s_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + (ob[j] ^ (h * 64)));
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + (oa[i] ^ (h * 64)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (h == 1 && wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             constexpr int H0 = (NI + 1) / 2;
-            // the second half of the activation fragments is read UNDER the first half's MFMAs
+            // PP: the fragments are in registers before the barrier that hands the matrix pipe over (and the stage back to the DMA)
+            auto pp_mid = [&]() {
+                if constexpr (PP) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
             if constexpr (!FP8) {
                 bf16x8_t fa[NI], fb[4];
 #pragma unroll
@@ -179,6 +285,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = H0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
+                pp_mid();
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < H0; ++i)
@@ -201,6 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = H0; i < NI; ++i) fa[i] = *(const i64x2_t*)(st + oa[i]);
+                pp_mid();
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < H0; ++i)
@@ -220,6 +328,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 __builtin_amdgcn_s_setprio(0);
             }
         }
+        if (PP && wr == 0) __builtin_amdgcn_s_barrier();      // pairs with row 1's last hand-over: the rows meet again at the epilogue
 
         // ---- epilogue, straight from the accumulators:  acc[i][j][r] = C[m0 + wr*WM + i*16 + fr][n0 + wc*64 + j*16 + 4*fg + r]
         int m0, n0;
@@ -347,11 +456,66 @@ static int p256_stages() {
     static const int n = [] { const char* e = getenv("MVULD_P256_STAGES"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
     return n;
 }
+// Ping-pong schedule of the two wave rows (template parameter PP): 1 = on (default), 0 = the lockstep loop.  Initialised from
+// MVULD_P256_PINGPONG; mvuld_set_gemm_p256_pingpong() overrides it (tests, A/B timing).  Results are bit-identical either way.
+#include <atomic>
+static std::atomic<int> g_p256_pp{-1};
+static bool p256_pingpong() {
+    int v = g_p256_pp.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_P256_PINGPONG");
+        v = e ? (atoi(e) != 0) : 1;
+        g_p256_pp.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mvuld_set_gemm_p256_pingpong(int on) {
+    g_p256_pp.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
+// 64-deep full-line stages (template parameter K64; bf16, K % 64 == 0): 1 = on, 0 = the 32-deep ring.  Initialised from MVULD_P256_K64;
+// mvuld_set_gemm_p256_k64() overrides it (tests, A/B timing).  Results are bit-identical either way.
+static std::atomic<int> g_p256_k64{-1};
+static bool p256_k64() {
+    int v = g_p256_k64.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_P256_K64");
+        v = e ? (atoi(e) != 0) : P256_K64_DEFAULT;
+        g_p256_k64.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mvuld_set_gemm_p256_k64(int on) {
+    g_p256_k64.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
 template <int EPI, int NI>
 static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int tiles_m = (int)cdiv(g.M, 32 * NI);
     const int nt = tiles_m * tiles_n;
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    if (p256_k64() && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb * 2 < ((int64_t)1 << 32)) {
+        constexpr int NS6 = NI <= 5 ? 3 : 2;
+        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
+        static const bool attr6 = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
+            return true;
+        }();
+        (void)attr6;
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n);
+        return;
+    }
+    if (p256_pingpong() && (NI > 7 || p256_stages() != 5)) {
+        static const bool attrp = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            return true;
+        }();
+        (void)attrp;
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        return;
+    }
     if constexpr (NI <= 7) {
         if (p256_stages() == 5) {
             constexpr int LDS5 = 5 * (2 * NI * 1024 + 16384) + 2048;
@@ -385,7 +549,6 @@ static void p256_launch_ni(const GemmArgs& g, int ni, int tiles_n, hipStream_t s
 
 // Routing of mvuld_gemm_nt to this kernel: 0 = never, 1 = default rule, 2 = whenever the shape is legal.  Initialised from
 // MVULD_GEMM_P256 (A/B runs of tools/gemm_shapes.py); mvuld_set_gemm_p256_mode() overrides it (tests).
-#include <atomic>
 static std::atomic<int> g_p256_mode{-1};
 static int p256_mode() {
     int m = g_p256_mode.load(std::memory_order_relaxed);
@@ -413,6 +576,15 @@ static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t strea
     const int tiles_m = (int)cdiv(g.M, 32 * NI);
     const int nt = tiles_m * tiles_n;
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    if (p256_pingpong()) {
+        static const bool attrp = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            return true;
+        }();
+        (void)attrp;
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        return;
+    }
     hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
 }
 static int p256_pick_ni(int M, int tiles_n, int cus);

@@ -1,8 +1,8 @@
 """GPU parity of individual C-ABI kernels against plain PyTorch fp32 on the CPU (sizes: seconds)."""
 import math
+import os
 
 import numpy as np
-
 import pytest
 import torch
 import torch.nn.functional as F
@@ -127,9 +127,14 @@ def _gemm_large_ragged(gpu, K):
     assert rel(out, ref * p.grad) < 1e-2
 
 
+K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "0"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
+
+
 @pytest.mark.parametrize("M,N,K,rows", [(6401, 2056, 544, 0), (6401, 2056, 544, 128), (6401, 2056, 544, 160), (6401, 2056, 544, 192),
                                          (6401, 2056, 544, 224), (6401, 2056, 544, 256), (20000, 1288, 160, 0), (20000, 1288, 160, 224),
-                                         (70000, 512, 128, 0), (70000, 512, 128, 160), (769, 520, 1024, 0)])
+                                         (70000, 512, 128, 0), (70000, 512, 128, 160), (769, 520, 1024, 0),
+                                         (6401, 2056, 576, 128), (6401, 2056, 576, 160), (6401, 2056, 576, 192), (6401, 2056, 576, 224),
+                                         (6401, 2056, 576, 256), (20000, 1288, 192, 0), (25088, 512, 2048, 0), (16384, 2304, 768, 0)])
 def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     """The persistent 256 x 256-tile kernel (csrc/gemm_p256.hip) forced on ragged shapes: M and N tails inside the last
     tiles, fewer tiles than CUs / several tiles per workgroup (the LDS-DMA ring and the bias slices run across tile
@@ -145,28 +150,60 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     ref = (A.float() @ B_.float().t()).cpu()
     hip.LIB.fn("mvuld_set_gemm_p256_mode")(2)
     hip.LIB.fn("mvuld_set_gemm_p256_rows")(rows)       # tile height: 0 = chosen per shape, else forced
+    pp = hip.LIB.fn("mvuld_set_gemm_p256_pingpong")
+    k64 = hip.LIB.fn("mvuld_set_gemm_p256_k64")
+    k64(0)
+
+    def both(**kw):
+        """The product under the ping-pong schedule (default) and under the lockstep one: same contraction order, so the bf16
+        matrices must be EQUAL; a mis-placed barrier or wait of either schedule reads a ring stage early and shows here or in the
+        repeated launches below."""
+        pp(1)
+        o1 = ops.gemm_nt(A, B_, **kw)
+        a1 = kw["aux"].clone() if kw.get("epi") == hip.EPI_GELU else None
+        pp(0)
+        o0 = ops.gemm_nt(A, B_, **kw)
+        pp(1)
+        assert torch.equal(o0, o1)
+        if a1 is not None:
+            assert torch.equal(a1, kw["aux"])
+        if K % 64 == 0:
+            # 64-deep full-line ring stages (two or three stages, two 32-deep sub-steps each): the same contraction order again
+            k64(1)
+            o2 = ops.gemm_nt(A, B_, **kw)
+            o3 = ops.gemm_nt(A, B_, **kw)
+            k64(0)
+            assert torch.equal(o2, o1) and torch.equal(o3, o1)
+            if a1 is not None:
+                assert torch.equal(a1, kw["aux"])
+        return o1
     try:
-        out = ops.gemm_nt(A, B_)
+        out = both()
         assert rel(out, ref) < 1e-2
         # exact structure check: identical operands through the older kernels must give the same bf16 matrix up to one rounding
         hip.LIB.fn("mvuld_set_gemm_p256_mode")(0)
         old = ops.gemm_nt(A, B_)
         hip.LIB.fn("mvuld_set_gemm_p256_mode")(2)
         assert float((out.float() - old.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
-        out = ops.gemm_nt(A, B_, bias=Bi)
+        out = both(bias=Bi)
         assert rel(out, ref + bias) < 1e-2
         aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
-        out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=aux)
+        out = both(bias=Bi, epi=hip.EPI_GELU, aux=aux)
         assert rel(aux, ref + bias) < 1e-2 and rel(out, F.gelu(ref + bias)) < 1e-2
-        out = ops.gemm_nt(A, B_, epi=hip.EPI_ADD_AUX, aux=P)
+        for _ in range(4):
+            again = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=torch.empty_like(aux))
+            assert torch.equal(again, out)
+        out = both(epi=hip.EPI_ADD_AUX, aux=P)
         assert rel(out, ref + pre.float()) < 1e-2
         p = pre.float().clone().requires_grad_(True)
         F.gelu(p).sum().backward()
-        out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_DGELU, aux=P)
+        out = both(epi=hip.EPI_MUL_DGELU, aux=P)
         assert rel(out, ref * p.grad) < 1e-2
     finally:
         hip.LIB.fn("mvuld_set_gemm_p256_mode")(1)
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
+        pp(1)
+        k64(K64_DEFAULT)
 
 
 @pytest.mark.parametrize("M,N,K", [(6401, 2056, 544), (20000, 1288, 160), (70000, 512, 128), (769, 520, 1024), (25088, 2048, 512), (300, 2048, 256),
@@ -282,6 +319,16 @@ def test_gemm_nt_fp8_vs_dequantised_product(gpu, M, N, K):
     aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
     out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux)
     assert rel(aux, ref + bias) < 4e-3 and rel(out, F.gelu(ref + bias)) < 1e-2
+    # the lockstep schedule of the main loop gives the same bytes as the ping-pong one (default), launch after launch
+    pp = hip.LIB.fn("mvuld_set_gemm_p256_pingpong")
+    try:
+        pp(0)
+        aux0 = torch.empty_like(aux)
+        assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux0), out) and torch.equal(aux0, aux)
+    finally:
+        pp(1)
+    for _ in range(3):
+        assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=torch.empty_like(aux)), out)
     # and the quantised product is a faithful stand-in for the bf16 one (e4m3: 3 mantissa bits, errors average out over K)
     full = (a.float() @ b.float().t())
     assert rel(ops.gemm_nt_fp8(qa, sa, qb, sb), full) < 6e-2
