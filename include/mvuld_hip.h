@@ -78,6 +78,9 @@ int mvuld_fp8_roll_scales(float* state, int n, mvuld_stream_t stream);
 /* CUs the 256x256 weight-gradient kernel plans its contraction splits for: 0 = all (best alone); the fused training step sets half
  * the chip while its streams run concurrently (a smaller footprint beside the data-gradient chain: step -1 %) */
 int mvuld_set_gemm_tn256_budget(int cus);
+/* Schedule of the 256x256 weight-gradient kernel's main loop: 1 (default) = ping-pong (the two waves of a SIMD half a slab step apart:
+ * one reads its transposed fragments while the other owns the matrix pipe), 0 = lockstep.  Bit-identical results; MVULD_TN256_PINGPONG. */
+int mvuld_set_gemm_tn256_pingpong(int on);
 int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
  * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */
@@ -86,7 +89,7 @@ int mvuld_set_gemm_p256_rows(int rows);
  * fragments from LDS while the other owns the matrix pipe; 0 = both in lockstep (one barrier per k-step).  Bit-identical results;
  * initialised from MVULD_P256_PINGPONG (A/B timing, tests). */
 int mvuld_set_gemm_p256_pingpong(int on);
-/* Ring geometry of that kernel for bf16 products with K % 64 == 0: 1 = 64-deep stages fetched as full 128-byte lines (8 rows x 128 bytes
+/* Ring geometry of that kernel for bf16 products with K % 64 == 0: 1 (default) = 64-deep stages fetched as full 128-byte lines (8 rows x 128 bytes
  * per LDS-DMA instruction; 2 stages, 3 at <= 160-row tiles), 0 = 32-deep stages (16 rows x 64 bytes per instruction, 4 stages).
  * Bit-identical results; initialised from MVULD_P256_K64. */
 int mvuld_set_gemm_p256_k64(int on);

@@ -17,6 +17,7 @@
 // M and N tails: DMA rows are clamped, stores predicated (N % 8 == 0).  K % 32 == 0.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define P_BN 256
 #ifndef P256_X
@@ -24,7 +25,7 @@
 #endif
 #define P_BK 32
 #ifndef P256_K64_DEFAULT
-#define P256_K64_DEFAULT 0
+#define P256_K64_DEFAULT 1
 #endif
 #define P_STAGE_BYTES 32768
 #define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     constexpr int STAGE = A_BYTES + 256 * RB;
     constexpr int BIAS_OFF = NS * STAGE;
     static_assert(K64 || NS == 4 || (NS == 5 && NI <= 7), "five stages only fit below 256 rows");
-    static_assert(!K64 || (PP && !FP8 && (NS == 2 || (NS == 3 && NI <= 5))), "64-deep stages: bf16, ping-pong, 2 stages (3 at <= 160 rows)");
+    static_assert(!K64 || (PP && (NS == 2 || (NS == 3 && NI <= 5))), "128-byte stages: ping-pong, 2 stages (3 at <= 160 rows)");
     static_assert(NS * STAGE + 2048 <= 163840, "ring does not fit the LDS");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,15 +243,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             issue_one();                                 // step cs + NS - 1 refills the stage step cs - 1 occupied
             const char* st = smem + (cs % NS) * STAGE;
             if constexpr (K64) {
-                // two 32-deep sub-steps, each a read epoch and a matrix epoch; row 1 runs one epoch behind row 0
-                bf16x8_t fa[NI], fb[4];
+                // two 64-byte sub-steps (32 bf16 / 64 e4m3 deep), each a read epoch and a matrix epoch; row 1 runs one epoch behind row 0
+                typedef typename std::conditional<FP8, i64x2_t, bf16x8_t>::type frag_t;
+                frag_t fa[NI], fb[4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (h == 1) __builtin_amdgcn_s_barrier();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8_t*)(st + (ob[j] ^ (h * 64)));
+                    for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(st + (ob[j] ^ (h * 64)));
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) fa[i] = *(const bf16x8_t*)(st + (oa[i] ^ (h * 64)));
+                    for (int i = 0; i < NI; ++i) fa[i] = *(const frag_t*)(st + (oa[i] ^ (h * 64)));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (h == 1 && wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1);
                     __builtin_amdgcn_s_barrier();
@@ -259,8 +261,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (FP8) {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][0], fa[i][0], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j][1], fa[i][1], acc[i][j], 0, 0, 0);
+                            } else {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                            }
+                        }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -474,7 +482,7 @@ extern "C" int mvuld_set_gemm_p256_pingpong(int on) {
     return 0;
 }
 
-// 64-deep full-line stages (template parameter K64; bf16, K % 64 == 0): 1 = on, 0 = the 32-deep ring.  Initialised from MVULD_P256_K64;
+// 64-deep full-line stages (template parameter K64; bf16, K % 64 == 0): 1 = on (default), 0 = the 32-deep ring.  Initialised from MVULD_P256_K64;
 // mvuld_set_gemm_p256_k64() overrides it (tests, A/B timing).  Results are bit-identical either way.
 static std::atomic<int> g_p256_k64{-1};
 static bool p256_k64() {
@@ -576,6 +584,17 @@ static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t strea
     const int tiles_m = (int)cdiv(g.M, 32 * NI);
     const int nt = tiles_m * tiles_n;
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
+    if (p256_k64() && g.K % 128 == 0 && (int64_t)g.M * g.lda < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb < ((int64_t)1 << 32)) {
+        constexpr int NS6 = NI <= 5 ? 3 : 2;
+        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
+        static const bool attr6 = [] {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, true, NS6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
+            return true;
+        }();
+        (void)attr6;
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n);
+        return;
+    }
     if (p256_pingpong()) {
         static const bool attrp = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);

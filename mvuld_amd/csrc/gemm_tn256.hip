@@ -29,6 +29,12 @@ typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
 // byte offset of element (row r, column c) of a [32][256] bf16 image whose 16-byte chunks are XOR-swizzled by the row
 __device__ __forceinline__ int t_off(int r, int c) { return r * 512 + ((((c >> 3) ^ (2 * (r & 7)))) << 4) + (c & 7) * 2; }
 
+// PP = ping-pong schedule (as in gemm_p256.hip): waves w and w + 4 (wr = 0 / 1) share a SIMD; with one barrier per slab both reach the 24
+// transposed reads together and then the 32 (+ 8) MFMAs together, and the matrix pipe idles through every read phase.  PP splits a slab
+// step into a read epoch and a matrix epoch and runs row 1 one epoch behind row 0.  Every wave still issues one slab of DMA per step
+// right after the barrier that opens its read epoch; slab c has been awaited by every wave before the barrier that opens row 0's read
+// epoch of c (row 1 waits for it at the end of its read epoch of c - 1, which closes with that barrier).  Same contraction order.
+template <bool PP>
 __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ dY, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
                                                        int M, int N, int K, int tiles_k, int nsplit, int per, float* __restrict__ slabs,
                                                        float* __restrict__ dW, int64_t ldw, float* __restrict__ dbias) {
@@ -100,11 +106,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int younger = nk - 1 - kt;
+    // slab x has landed once at most the slabs issued after it are in flight (precondition: this wave has issued up to slab x + 2)
+    auto wait_slab = [&](int x) {
+        const int younger = nk - 1 - x;
         if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (PP && wr == 1) {                                 // row 1 falls one barrier epoch behind row 0
+        wait_slab(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!PP || wr == 0) wait_slab(kt);
         __builtin_amdgcn_s_barrier();                    // slab kt visible to every wave; every wave is done with slab kt - 1
         issue_one();                                     // slab kt + 3 refills the stage slab kt - 1 occupied
         const char* st = smem + (kt & 3) * T_STAGE_BYTES;
@@ -121,7 +135,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
             const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + oa[i] + 16 * 512));
             fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
+        if constexpr (PP) {
+            // the fragments are in registers before the barrier that hands the matrix pipe over (and the stage back to the DMA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (wr == 1 && kt + 1 < nk) wait_slab(kt + 1);
+            __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PP) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -131,7 +152,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
         }
+        if constexpr (PP) __builtin_amdgcn_s_setprio(0);
     }
+    if (PP && wr == 0) __builtin_amdgcn_s_barrier();     // pairs with row 1's last hand-over
 
     // bias gradient: every column of accb[i] holds sum_m dY[m][n]; lanes of column 0 add the split's share
     if (do_bias && fr == 0) {
@@ -207,6 +230,22 @@ static int tn256_num_cus() {
     return b > 0 && b < tn256_all_cus() ? b : tn256_all_cus();
 }
 
+// schedule of the main loop: 1 (default) = ping-pong, 0 = lockstep; MVULD_TN256_PINGPONG, mvuld_set_gemm_tn256_pingpong (tests, A/B timing)
+static std::atomic<int> g_tn256_pp{-1};
+static bool tn256_pingpong() {
+    int v = g_tn256_pp.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_TN256_PINGPONG");
+        v = e ? (atoi(e) != 0) : 1;
+        g_tn256_pp.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mvuld_set_gemm_tn256_pingpong(int on) {
+    g_tn256_pp.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
 // split plan of the 256 x 256-tile kernel: 0 splits = shape not eligible
 static void tn256_plan(int M, int N, int K, int& nsplit, int& per) {
     nsplit = 0;
@@ -243,14 +282,19 @@ int mvuld_gemm_tn256_try(const void* dY, int64_t ldy, const void* X, int64_t ldx
     const int64_t need = mvuld_gemm_tn256_workspace_bytes(M, N, K);
     if (nsplit > 1 && (!ws || ws_bytes < need || (((uintptr_t)ws) & 15) != 0)) return -1;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)gemm_tn256_k, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         return true;
     }();
     (void)attr;
     const int tiles_k = (int)cdiv(K, 256);
     const int tiles = (int)(cdiv(N, 256) * tiles_k);
-    hipLaunchKernelGGL(gemm_tn256_k, dim3(tiles * nsplit), dim3(512), T_LDS_BYTES, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, M, N, K,
-                       tiles_k, nsplit, per, (float*)ws, dW, ldw, dbias);
+    if (tn256_pingpong())
+        hipLaunchKernelGGL(gemm_tn256_k<true>, dim3(tiles * nsplit), dim3(512), T_LDS_BYTES, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, M, N,
+                           K, tiles_k, nsplit, per, (float*)ws, dW, ldw, dbias);
+    else
+        hipLaunchKernelGGL(gemm_tn256_k<false>, dim3(tiles * nsplit), dim3(512), T_LDS_BYTES, stream, (const bf16*)dY, ldy, (const bf16*)X, ldx, M, N,
+                           K, tiles_k, nsplit, per, (float*)ws, dW, ldw, dbias);
     if (nsplit > 1)
         hipLaunchKernelGGL(gemm_tn256_reduce_k, dim3(tiles * 64), dim3(256), 0, stream, (const float*)ws, nsplit, tiles_k, N, K, dW, ldw);
     return 0;

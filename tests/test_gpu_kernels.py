@@ -127,7 +127,7 @@ def _gemm_large_ragged(gpu, K):
     assert rel(out, ref * p.grad) < 1e-2
 
 
-K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "0"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
+K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "1"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
 
 
 @pytest.mark.parametrize("M,N,K,rows", [(6401, 2056, 544, 0), (6401, 2056, 544, 128), (6401, 2056, 544, 160), (6401, 2056, 544, 192),
@@ -320,13 +320,17 @@ def test_gemm_nt_fp8_vs_dequantised_product(gpu, M, N, K):
     out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux)
     assert rel(aux, ref + bias) < 4e-3 and rel(out, F.gelu(ref + bias)) < 1e-2
     # the lockstep schedule of the main loop gives the same bytes as the ping-pong one (default), launch after launch
-    pp = hip.LIB.fn("mvuld_set_gemm_p256_pingpong")
+    # (K % 128 == 0: the default is the 128-byte full-line ring; otherwise the 64-byte ring under the ping-pong schedule)
+    pp, k64 = hip.LIB.fn("mvuld_set_gemm_p256_pingpong"), hip.LIB.fn("mvuld_set_gemm_p256_k64")
     try:
-        pp(0)
-        aux0 = torch.empty_like(aux)
-        assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux0), out) and torch.equal(aux0, aux)
+        for sched in ((0, 1), (0, 0)):                   # (k64, pingpong)
+            k64(sched[0])
+            pp(sched[1])
+            aux0 = torch.empty_like(aux)
+            assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux0), out) and torch.equal(aux0, aux)
     finally:
         pp(1)
+        k64(K64_DEFAULT)
     for _ in range(3):
         assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=torch.empty_like(aux)), out)
     # and the quantised product is a faithful stand-in for the bf16 one (e4m3: 3 mantissa bits, errors average out over K)
@@ -857,9 +861,23 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         ops.linear_wgrad(gdy, gx, w, b)
         assert rel(w.grad, 3.0 * ref + 1.0) < 2e-3
         assert rel(b.grad, 3.0 * dy.sum(0) + 1.0) < 2e-3
+        if mode == "tn256":
+            # ping-pong (default) and lockstep schedules of the 256 x 256 kernel contract in the same order: equal weight gradients, and
+            # equal again on a repeated launch (a mis-placed wait reads a slab before its DMA has landed); the bias gradient is fp32
+            # atomics from the splits, equal up to their order
+            res = []
+            for on in (1, 0, 1):
+                hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(on)
+                w.grad.zero_()
+                b.grad.zero_()
+                ops.linear_wgrad(gdy, gx, w, b)
+                res.append((w.grad.clone(), b.grad.clone()))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+            assert rel(res[0][1], res[1][1]) < 1e-5
     finally:
         ops.USE_TN_SLABS[0] = True
         hip.LIB.fn("mvuld_set_gemm_tn256")(1)
+        hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(1)
 
 
 @pytest.mark.parametrize("B,h,w,S", [(2, 600, 800, 448), (1, 300, 200, 448), (3, 448, 448, 448), (1, 1000, 448, 448), (2, 97, 1301, 448),
