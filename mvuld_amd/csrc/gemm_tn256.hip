@@ -230,13 +230,15 @@ static int tn256_num_cus() {
     return b > 0 && b < tn256_all_cus() ? b : tn256_all_cus();
 }
 
-// schedule of the main loop: 1 (default) = ping-pong, 0 = lockstep; MVULD_TN256_PINGPONG, mvuld_set_gemm_tn256_pingpong (tests, A/B timing)
+// schedule of the main loop: 0 (default) = lockstep, 1 = ping-pong; MVULD_TN256_PINGPONG, mvuld_set_gemm_tn256_pingpong (tests, A/B timing).
+// Measured (tools/gemm_shapes.py --only tn, same box): ping-pong 12.25 ms per step's worth against 12.13 ms in lockstep (+1 %, +2..3 % on the
+// long-contraction shapes) -- unlike the NT kernel this loop does not lose its time to the read / MFMA alternation, so the extra barrier only costs.
 static std::atomic<int> g_tn256_pp{-1};
 static bool tn256_pingpong() {
     int v = g_tn256_pp.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("MVULD_TN256_PINGPONG");
-        v = e ? (atoi(e) != 0) : 1;
+        v = e ? (atoi(e) != 0) : 0;
         g_tn256_pp.store(v, std::memory_order_relaxed);
     }
     return v != 0;
