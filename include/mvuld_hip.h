@@ -73,7 +73,7 @@ int mvuld_layernorm_fwd_q8(const void* x, const void* pre, void* xsum, const flo
 int mvuld_fp8_roll_scales(float* state, int n, mvuld_stream_t stream);
 
 /* Routing of mvuld_gemm_nt's bf16 -> bf16 plain-store products to the persistent 256 x 256-tile kernel (csrc/gemm_p256.hip):
- * 0 = never, 1 = default rule (>= 160 tiles, N % 128 == 0: the tall Linear layers of the two encoders, same call sites as
+ * 0 = never, 1 = default rule (>= 96 tiles, N % 128 == 0, at most half of the last column tile empty: the tall Linear layers of the two encoders, same call sites as
  * mvuld_gemm_nt), 2 = every legal shape (K % 32 == 0, K >= 128, N % 8 == 0, no ELU epilogues; tests and A/B timing).  Host-side setting, no stream. */
 /* CUs the 256x256 weight-gradient kernel plans its contraction splits for: 0 = all (best alone); the fused training step sets half
  * the chip while its streams run concurrently (a smaller footprint beside the data-gradient chain: step -1 %) */

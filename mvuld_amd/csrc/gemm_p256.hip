@@ -665,9 +665,13 @@ int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream)
     if (g.epi == EPI_ELU || g.epi == EPI_MUL_DELU) return -1;      // head-only epilogues: small products, not this kernel's
     const int tiles_n = (int)cdiv(g.N, P_BN);
     if (mode == 1) {
-        // default rule: enough whole tiles to occupy most of the chip, and little of the last column tile wasted
-        if (cdiv(g.M, 256) * tiles_n < 160 || g.N % 128 != 0) return -1;
-        if ((int64_t)tiles_n * P_BN > (int64_t)g.N * 5 / 4) return -1;
+        // default rule: enough whole tiles to occupy a good part of the chip, and not too much of the last column tile wasted.
+        // Measured with the full-line ring (tools/gemm_shapes.py --p256-mode 2 against the rings of gemm.hip, same run): the 100-tile
+        // products of the last Swin stage (6272 x 1024) are 13-20 % faster here, and the stage-0 products with N = 384 / 128 (the
+        // second / only column tile half empty: wasted MFMAs, but these are streaming-bound) 30 % / 15-22 % faster.
+        const int64_t tiles = cdiv(g.M, 256) * tiles_n;
+        if (tiles < 96 || g.N % 128 != 0) return -1;
+        if ((int64_t)tiles_n * P_BN * 2 > (int64_t)g.N * (tiles >= 1024 ? 4 : 3)) return -1;
     }
     int ni = g_p256_ni.load(std::memory_order_relaxed);
     if (ni == 0 && mvuld_gemm_nt_p128d_try(g, stream) == 0) return 0;      // wide output, short contraction: deferred-epilogue kernel

@@ -31,7 +31,7 @@ def short(n):
 
 def kernel_stats(sub, out):
     import glob
-    rows = list(csv.DictReader(open(glob.glob(f"{src}/{sub}/*kernel_stats.csv")[0])))
+    rows = list(csv.DictReader(open(glob.glob(f"{src}/{sub}/**/*kernel_stats.csv", recursive=True)[0])))
     with open(out, "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
@@ -48,7 +48,7 @@ if os.path.isdir(f"{src}/kt2"):
 agg = collections.defaultdict(lambda: {"n": 0, "fetch": 0.0, "write": 0.0, "ns": 0})
 for kind in ("fetch", "write"):
     import glob
-    ps = glob.glob(f"{src}/{kind}/*counter_collection.csv")
+    ps = glob.glob(f"{src}/{kind}/**/*counter_collection.csv", recursive=True)
     if not ps:
         continue
     p = ps[0]
