@@ -13,6 +13,11 @@
  *     retrievable through mvuld_last_error() (thread-local).
  *   - "atomic accumulate" outputs (parameter gradients) are fp32 and must be zeroed by the caller
  *     once per optimisation step.
+ *   - the only process-wide state is a handful of ROUTING / TUNING settings (mvuld_set_*: which of several
+ *     equivalent kernels or schedules a call uses).  Each is one atomic integer, read once from its MVULD_*
+ *     environment variable on first use unless a setter ran first (function-local statics / atomics: safe to
+ *     call from several threads); none of them changes what a call computes beyond the rounding order noted
+ *     at its declaration, and kernel launches themselves keep no state.
  */
 #ifndef MVULD_HIP_H
 #define MVULD_HIP_H

@@ -18,6 +18,7 @@
 // accumulated with LDS float atomics per workgroup and flushed with one global atomic per touched entry.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 struct AttnGeom {
     int mode, B, H, N, nW, res, ws, shift;
@@ -1148,8 +1149,7 @@ static int am_split(int64_t groups, int ntile) {
     // Query / key tiles of one (window, head) are split over several workgroups only while there are fewer workgroups than
     // ~2 per CU: every split re-stages the whole K/V (or Q~/dO) tile.  (1024 measured 14-25 % slower than 512 on the 512-group
     // stage-2 layers and the 384-group text encoder.)
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("MVULD_ATTN_SPLIT_TARGET"); target = e ? atoi(e) : 512; }
+    static const int target = [] { const char* e = getenv("MVULD_ATTN_SPLIT_TARGET"); return e ? atoi(e) : 512; }();      // once, thread-safe
     int s = 1;
     while (groups * s < target && s * 2 * 8 <= ntile) s *= 2;
     return s;
@@ -1161,16 +1161,23 @@ static int am_split(int64_t groups, int ntile) {
 // MVULD_ATTN_TAIL_SPLIT / mvuld_set_attn_tail_split: 1 = balance the last round, 0 = off (default).  Measured on the text encoder's 384
 // groups: forward 73.3 vs 73.8 us, backward 177.9 vs 179.9 us, whole step 60.4 vs 60.2 ms -- re-staging K/V for the halves costs what the
 // emptier round saved, and beside other streams the half-empty round was never idle.  Bit-identical either way (tests).
-static int g_am_tail = -1;
+static std::atomic<int> g_am_tail{-1};
 extern "C" int mvuld_set_attn_tail_split(int on) {
-    g_am_tail = on ? 1 : 0;
+    g_am_tail.store(on ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }
 static void am_plan(AttnGeom& g, int64_t groups, int ntile, int& split, unsigned& grid) {
-    static int cus = 0;
-    if (!cus) { int dev = 0, v = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); cus = v > 0 ? v : 256; }
-    if (g_am_tail < 0) { const char* e = getenv("MVULD_ATTN_TAIL_SPLIT"); g_am_tail = e ? (atoi(e) ? 1 : 0) : 0; }
-    const int tail = g_am_tail;
+    static const int cus = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    int tail = g_am_tail.load(std::memory_order_relaxed);
+    if (tail < 0) {
+        const char* e = getenv("MVULD_ATTN_TAIL_SPLIT");
+        tail = e ? (atoi(e) ? 1 : 0) : 0;
+        g_am_tail.store(tail, std::memory_order_relaxed);
+    }
     split = am_split(groups, ntile);
     g.whole = 0;
     grid = (unsigned)(groups * split);
@@ -1225,8 +1232,7 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
     am_plan(g, (int64_t)B * nW * H, (N + 15) / 16, qsplit, nwg);
     dim3 grid(nwg);
     // 16 waves (4 per SIMD) hide the LDS / MFMA latencies of the score loop twice as well as 8; MVULD_ATTN_FWD_THREADS overrides
-    static int fwd_threads = 0;
-    if (!fwd_threads) { const char* e = getenv("MVULD_ATTN_FWD_THREADS"); fwd_threads = e ? atoi(e) : 1024; }
+    static const int fwd_threads = [] { const char* e = getenv("MVULD_ATTN_FWD_THREADS"); const int v = e ? atoi(e) : 1024; return v > 0 ? v : 1024; }();
 #define AM_FWD(HDV, MODEV, MASKV)                                                                              \
     do {                                                                                                        \
         if (am_set_lds(attn_fwd_mfma_k<HDV, MODEV, MASKV>, bytes, "attn_fwd_mfma_k")) return 1;                 \
@@ -1295,8 +1301,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         MV_CHECK_ARG(hd == 32 && ws <= 32, "attn_bwd_mfma: the bias-table gradient pass covers head_dim 32 and windows up to 32x32");
         const size_t bytes = (size_t)2 * Npad * (hd + 8) * 2 + (size_t)Npad * 4 + (size_t)2 * T2 * 4;
         // dy per work item: 4 (ws = 28 -> 7 groups x 2 q parts = 14 items on 8 waves, 250 VGPRs) or 2 (28 items on 16 waves, 128 VGPRs)
-        static int dbias_g = 0;
-        if (!dbias_g) { const char* e = getenv("MVULD_ATTN_DBIAS_G"); dbias_g = e ? atoi(e) : 4; }
+        static const int dbias_g = [] { const char* e = getenv("MVULD_ATTN_DBIAS_G"); return e ? atoi(e) : 4; }();
         const int DG = dbias_g == 2 ? 2 : 4;
         const int items = ((ws + DG - 1) / DG) * ((ws + 15) / 16);
         int sp = 1;

@@ -1150,10 +1150,10 @@ extern "C" int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, in
 }
 
 // ------------------------------------------------------------------------------------ C ABI
-static int g_k256 = -1;     // minimum K for the 256 x 256 ring kernel (0 = never); -1 = read MVULD_GEMM_256 on first use
+static std::atomic<int> g_k256{-1};     // minimum K for the 256 x 256 ring kernel (0 = never); -1 = read MVULD_GEMM_256 on first use
 
 extern "C" int mvuld_set_gemm_256_min_k(int min_k) {
-    g_k256 = min_k < 0 ? 0 : min_k;
+    g_k256.store(min_k < 0 ? 0 : min_k, std::memory_order_relaxed);
     return 0;
 }
 
@@ -1184,17 +1184,21 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
         if (mvuld_gemm_nt_p256_try(g, dtype_out, stream) == 0) { MV_LAUNCH_CHECK("gemm_nt_bf16_p256"); return 0; }
         // 256 x 256 LDS-DMA ring kernel: opt-in (mvuld_set_gemm_256_min_k / MVULD_GEMM_256 = minimum K, 0 = off, the default:
         // in the full step it is a wash -- faster alone from K >= 1536, slower cold and on partial last rounds at 1 workgroup / CU)
-        if (g_k256 < 0) { const char* e = getenv("MVULD_GEMM_256"); g_k256 = e ? atoi(e) : 0; }
-        const int k256 = g_k256;
+        int k256 = g_k256.load(std::memory_order_relaxed);
+        if (k256 < 0) {
+            const char* e = getenv("MVULD_GEMM_256");
+            k256 = e ? atoi(e) : 0;
+            g_k256.store(k256, std::memory_order_relaxed);
+        }
         const int tiles_m2 = (int)cdiv(M, G2_BM), tiles_n2 = (int)cdiv(N, G2_BN);
         if (k256 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= k256 && (int64_t)tiles_m2 * tiles_n2 * batch >= 128) {
             dim3 grid2(tiles_m2 * tiles_n2, batch);
-            static bool attr2 = false;
-            if (!attr2) {
+            static const bool attr2 = [] {               // function-local static: initialised once, thread-safe (C++11)
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_256<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_256<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-                attr2 = true;
-            }
+                return true;
+            }();
+            (void)attr2;
             if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16_256<float>), grid2, dim3(512), G2_LDS_BYTES, stream, g, tiles_m2, tiles_n2);
             else hipLaunchKernelGGL((gemm_nt_mfma_bf16_256<bf16>), grid2, dim3(512), G2_LDS_BYTES, stream, g, tiles_m2, tiles_n2);
             MV_LAUNCH_CHECK("gemm_nt_mfma_bf16_256");
@@ -1207,33 +1211,30 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
         // long-K ones (K = 3072 / 4096: 10-15 % better there, its 64-deep steps halve the barriers per FLOP).
         // 256 x 128 LDS-DMA ring (two 8-wave workgroups / CU, 85 FLOP per L2 byte) whenever the taller tiles still fill the chip:
         // 3-15 % over the 128 x 128 ring on every shape of the step, -1.8 ms per step.  MVULD_GEMM_RING256X128 = minimum K (0 = off).
-        static int ring4 = -1;
-        if (ring4 < 0) { const char* e = getenv("MVULD_GEMM_RING256X128"); ring4 = e ? atoi(e) : 32; }
-        static int ring4_tiles = -1;
-        if (ring4_tiles < 0) { const char* e = getenv("MVULD_GEMM_RING256X128_TILES"); ring4_tiles = e ? atoi(e) : 256; }
+        static const int ring4 = [] { const char* e = getenv("MVULD_GEMM_RING256X128"); return e ? atoi(e) : 32; }();
+        static const int ring4_tiles = [] { const char* e = getenv("MVULD_GEMM_RING256X128_TILES"); return e ? atoi(e) : 256; }();
         if (ring4 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= ring4 && (int64_t)cdiv(M, G4_BM) * tiles_n * batch >= ring4_tiles) {
             const int tm4 = (int)cdiv(M, G4_BM);
-            static bool attr4 = false;
-            if (!attr4) {
+            static const bool attr4 = [] {
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring256x128<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring256x128<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);
-                attr4 = true;
-            }
+                return true;
+            }();
+            (void)attr4;
             if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring256x128<float>), dim3(tm4 * tiles_n, batch), dim3(512), G4_LDS_BYTES, stream, g, tm4, tiles_n);
             else hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring256x128<bf16>), dim3(tm4 * tiles_n, batch), dim3(512), G4_LDS_BYTES, stream, g, tm4, tiles_n);
             MV_LAUNCH_CHECK("gemm_nt_mfma_bf16_ring256x128");
             return 0;
         }
-        static int ring = -1;
-        if (ring < 0) { const char* e = getenv("MVULD_GEMM_RING_MAXK"); ring = e ? atoi(e) : 2304; }
+        static const int ring = [] { const char* e = getenv("MVULD_GEMM_RING_MAXK"); return e ? atoi(e) : 2304; }();
         if (splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K <= ring) {
             dim3 grid3(tiles_m * tiles_n, batch);
-            static bool attr3 = false;
-            if (!attr3) {
+            static const bool attr3 = [] {
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring128<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
                 (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_ring128<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
-                attr3 = true;
-            }
+                return true;
+            }();
+            (void)attr3;
             if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring128<float>), grid3, dim3(256), G3_LDS_BYTES, stream, g, tiles_m, tiles_n);
             else hipLaunchKernelGGL((gemm_nt_mfma_bf16_ring128<bf16>), grid3, dim3(256), G3_LDS_BYTES, stream, g, tiles_m, tiles_n);
             MV_LAUNCH_CHECK("gemm_nt_mfma_bf16_ring128");
@@ -1243,18 +1244,17 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
         // LDS-DMA loop (one barrier per k-step; the near-fp32 head GEMMs: -6 %); everything else the single-buffer loop at
         // 3 workgroups / CU, whose extra resident tile hides prologue / epilogue better than the deeper pipeline does (A/B in the
         // full step: equal or better).  MVULD_GEMM_NBUF=1|2|3 forces single | double | double + LDS-DMA.
-        static int forced = -1;
-        if (forced < 0) { const char* e = getenv("MVULD_GEMM_NBUF"); forced = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
+        static const int forced = [] { const char* e = getenv("MVULD_GEMM_NBUF"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }();
         const bool small_grid = (int64_t)tiles_m * tiles_n * batch * splitk <= 512;
         const int variant = forced ? forced : (K >= 1024 && K % GT_BK == 0 && small_grid ? 3 : 1);
-        static bool attr = false;
-        if (!attr) {
+        static const bool attr = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<float, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
             (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16<bf16, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES_N(2));
-            attr = true;
-        }
+            return true;
+        }();
+        (void)attr;
         if (variant == 3 && K % GT_BK == 0) {
             if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16<float, 2, true>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);
             else hipLaunchKernelGGL((gemm_nt_mfma_bf16<bf16, 2, true>), grid, dim3(256), GT_LDS_BYTES_N(2), stream, g, tiles_m, tiles_n);

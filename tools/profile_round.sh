@@ -13,13 +13,13 @@ mkdir -p $O
 B="$R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-varlen --no-infer"
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
     rm -rf $O/kt $O/kt2 $O/fetch $O/write
-    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -- python3 $B > $O/kt.log 2>&1
+    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt -- python3 $B > $O/kt.log 2>&1
     echo "kt done"
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt2 -- python3 $B > $O/kt2.log 2>&1
+    timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt2 -- python3 $B > $O/kt2.log 2>&1
     echo "kt2 done"
-    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -- python3 $B > $O/fetch.log 2>&1
+    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $O/fetch -- python3 $B > $O/fetch.log 2>&1
     echo "fetch done"
-    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -- python3 $B > $O/write.log 2>&1
+    MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $O/write -- python3 $B > $O/write.log 2>&1
     echo "write done"
 fi
 if [ "$WHAT" = shapes ] || [ "$WHAT" = all ]; then
@@ -27,15 +27,16 @@ if [ "$WHAT" = shapes ] || [ "$WHAT" = all ]; then
     G="$R/tools/gemm_shapes.py --reps 5"
     timeout -k 10 200 python3 $G --csv $O/gemm_shapes_timings.csv > $O/gs.log 2>&1
     echo "gs timings done"
-    timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $O/gs_pmc/p1 -- python3 $G > $O/gs_pmc1.log 2>&1
+    timeout -k 10 300 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace -d $O/gs_pmc/p1 -- python3 $G > $O/gs_pmc1.log 2>&1
     echo "gs pmc1 done"
-    timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY --kernel-trace -d $O/gs_pmc/p2 -- python3 $G > $O/gs_pmc2.log 2>&1
+    timeout -k 10 300 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY --kernel-trace -d $O/gs_pmc/p2 -- python3 $G > $O/gs_pmc2.log 2>&1
     echo "gs pmc2 done"
-    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/gs_traf/p1 -- python3 $G > $O/gs_traf1.log 2>&1
+    timeout -k 10 300 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $O/gs_traf/p1 -- python3 $G > $O/gs_traf1.log 2>&1
     echo "gs fetch done"
-    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/gs_traf/p2 -- python3 $G > $O/gs_traf2.log 2>&1
+    timeout -k 10 300 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $O/gs_traf/p2 -- python3 $G > $O/gs_traf2.log 2>&1
     echo "gs write done"
 fi
-# keep what travels back small: counter CSVs and stats only
+# keep what travels back small: stats and counter CSVs only (the per-dispatch kernel traces of the bench runs are tens of MB)
 find $O -name "*.db" -delete 2>/dev/null || true
+find $O/kt $O/kt2 -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null || true
 du -sh $O
