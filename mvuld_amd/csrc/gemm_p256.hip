@@ -21,7 +21,7 @@
 
 #define P_BN 256
 #ifndef P256_X
-#define P256_X 0      // timing experiments (tools/p256_variants.sh): bit 0 = epilogue without its stores, bit 1 = without GELU / dGELU math
+#define P256_X 0      // timing experiments (tools/p256_variants.sh): bit 0 = epilogue without its stores, bit 1 = without GELU / dGELU math, bit 2 = non-temporal stores
 #endif
 #define P_BK 32
 #ifndef P256_K64_DEFAULT
@@ -47,6 +47,13 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// 16-byte output store; P256_X bit 2 (timing experiment): non-temporal, so that the output stream does not displace the weights in L2
+typedef unsigned __attribute__((ext_vector_type(4))) p_u32x4_t;
+__device__ __forceinline__ void p_st16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+    const p_u32x4_t v = {a, b, c, d};
+    if (P256_X & 4) __builtin_nontemporal_store(v, (p_u32x4_t*)p);
+    else *(p_u32x4_t*)p = v;
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NI = 16-row accumulator fragments per wave along M: the tile is (32 * NI) x 256, NI = 8 -> 256 x 256.  The host picks NI per
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 if (C) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][0], v[0][1]), pk_bf16(v[1][0], v[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][2], v[0][3]), pk_bf16(v[1][2], v[1][3]), false, false);
-                    if (ok) *(uint4*)(C + (int64_t)row * g.ldc + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (ok) p_st16(C + (int64_t)row * g.ldc + col, s0[0], s1[0], s0[1], s1[1]);
                     if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
                 if constexpr (FP8 && EPI == EPI_GELU) {
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 if (EPI == EPI_GELU && aux) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][2], pre[0][3]), pk_bf16(pre[1][2], pre[1][3]), false, false);
-                    if (ok) *(uint4*)(aux + (int64_t)row * g.ldaux + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (ok) p_st16(aux + (int64_t)row * g.ldaux + col, s0[0], s1[0], s0[1], s1[1]);
                     if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
             }
@@ -506,6 +513,20 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
     if (p256_k64() && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb * 2 < ((int64_t)1 << 32)) {
         constexpr int NS6 = NI <= 5 ? 3 : 2;
+        if constexpr (NI <= 5) {
+            // MVULD_P256_K64_NS2=1: two stages below 192 rows too (A/B of the ring depth on one tile shape)
+            static const bool two = [] { const char* e = getenv("MVULD_P256_K64_NS2"); return e && atoi(e) != 0; }();
+            if (two) {
+                constexpr int LDS2 = 2 * (NI * 4096 + 32768) + 2048;
+                static const bool attr2 = [] {
+                    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+                    return true;
+                }();
+                (void)attr2;
+                hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>), dim3(grid), dim3(512), LDS2, stream, g, tiles_m, tiles_n);
+                return;
+            }
+        }
         constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
         static const bool attr6 = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
