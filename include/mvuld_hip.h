@@ -99,6 +99,10 @@ int mvuld_set_gemm_p256_pingpong(int on);
  * per LDS-DMA instruction; 2 stages, 3 at <= 160-row tiles), 0 = 32-deep stages (16 rows x 64 bytes per instruction, 4 stages).
  * Bit-identical results; initialised from MVULD_P256_K64. */
 int mvuld_set_gemm_p256_k64(int on);
+/* Full-line ring only: 1 = every wave issues the next tile's last prefetched step BEFORE its epilogue's stores (vmcnt retires in issue
+ * order: the stores then never sit in front of a load that is waited for within the tile's first steps), 0 = after them.
+ * Bit-identical results; initialised from MVULD_P256_EARLY. */
+int mvuld_set_gemm_p256_early(int on);
 /* routing of mvuld_gemm_nt to the experimental deferred-epilogue 128 x 256 kernel (gemm_p128d.hip; measured slower than the 256-row
  * kernel, see its header): 0 never (default), 1 rule (N >= 1536, K <= 1024, >= 2 tiles per CU), 2 whenever the shape is legal;
  * initialised from MVULD_GEMM_P128D */

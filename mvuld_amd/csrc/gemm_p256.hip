@@ -27,6 +27,9 @@
 #ifndef P256_K64_DEFAULT
 #define P256_K64_DEFAULT 1
 #endif
+#ifndef P256_EARLY_DEFAULT
+#define P256_EARLY_DEFAULT 0
+#endif
 #define P_STAGE_BYTES 32768
 #define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
 #define P_LDS_BYTES (4 * P_STAGE_BYTES + 2048)
@@ -81,7 +84,14 @@ typedef long __attribute__((ext_vector_type(2))) i64x2_t;
 // read still covers all 64 banks), a stage is (32 NI + 256) rows x 128 bytes and is consumed as two 32-deep sub-steps (the second one's
 // chunk index is the first one's ^ 4: byte offset ^ 64), so the contraction order -- and every output bit -- is that of the 32-deep ring.
 // Stages: 2 at NI >= 6 (2 x 64 KiB at NI = 8), 3 at NI <= 5 (3 x 52 KiB at NI = 5).
-template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false>
+// EI = early issue (K64 only).  vmcnt retires in issue order, so an operand load issued after an epilogue's stores is only counted as landed
+// once those stores are acknowledged.  The two-stage full-line ring issues the next tile's second step after the stores (at that tile's
+// first barrier) and waits for it one 64-deep step later: the stores get one step (~1 us) to drain instead of the 32-deep ring's three.
+// With EI every wave issues that step BEFORE its epilogue -- right after the last hand-over barrier of the tile, when the stage the
+// last step occupied has been read by every wave -- and skips the issue at the next tile's first barrier.  The stores are then younger
+// than every load in flight: the first NS steps of a tile may leave them pending (NS - 1 before), a K = 128 tile never waits for its
+// predecessor's stores at all.  The DMA stream then runs up to two tiles ahead, hence three bias slices instead of two.
+template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false, bool EI = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
@@ -93,7 +103,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     constexpr int BIAS_OFF = NS * STAGE;
     static_assert(K64 || NS == 4 || (NS == 5 && NI <= 7), "five stages only fit below 256 rows");
     static_assert(!K64 || (PP && (NS == 2 || (NS == 3 && NI <= 5))), "128-byte stages: ping-pong, 2 stages (3 at <= 160 rows)");
-    static_assert(NS * STAGE + 2048 <= 163840, "ring does not fit the LDS");
+    static_assert(!EI || K64, "early issue belongs to the full-line ring");
+    constexpr int NBS = EI ? 3 : 2;                     // bias slices
+    static_assert(NS * STAGE + NBS * 1024 <= 163840, "ring does not fit the LDS");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // 2 x 4 waves, WM (m) x 64 (n) each
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         // vmcnt(0)); older than the tile's first operand stage, so the wait that retires that stage retires it too
         if (g.bias && wave == 0) {
             const int c = n0 + 4 * lane;
-            __builtin_amdgcn_global_load_lds((glb_vp)(g.bias + (c < g.N ? c : 0)), (lds_vp)(smem + BIAS_OFF + (ord & 1) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(g.bias + (c < g.N ? c : 0)), (lds_vp)(smem + BIAS_OFF + (ord % NBS) * 1024), 16, 0, 0);
         }
     };
     auto issue_one = [&]() {
@@ -209,9 +221,34 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     // between step xcs's loads and now -- counting them lets the stores drain under the MFMAs instead of in front of them.  vmcnt
     // retires in issue order, so from the fourth step on the stores are older than the awaited loads and must be complete.
     // Precondition (both schedules): this wave has issued the DMA up to step xcs + NS - 2 and nothing younger.
-    auto wait_step = [&](int xkt, int xcs) {
+    // EI: `prev` = the tile follows another one of this workgroup, whose end issued this tile's step NS - 1 ahead of its stores
+    auto wait_step = [&](int xkt, int xcs, bool prev) {
         const int younger = total - 1 - xcs;
         constexpr int AH = NS - 2;                       // k-steps allowed to stay in flight behind the awaited one
+        if constexpr (EI) {
+            int steps = AH + ((prev && xkt == 0) ? 1 : 0);
+            if (steps > younger) steps = younger;
+            const int st = (prev && xkt <= NS - 1) ? pend : 0;
+#define P_W(S, P)                                                                                               \
+    do {                                                                                                        \
+        constexpr int HI = (S) * OPS_HI + (P) > 63 ? 63 : (S) * OPS_HI + (P);                                    \
+        constexpr int LO = (S) * OPS_LO + (P) > 63 ? 63 : (S) * OPS_LO + (P);                                    \
+        if (a2) wait_vm<HI>(); else wait_vm<LO>();                                                              \
+    } while (0)
+#define P_WS(S)                                                                                                 \
+    do {                                                                                                        \
+        if (st == ST1) P_W(S, ST1);                                                                             \
+        else if (st == ST2) P_W(S, ST2);                                                                        \
+        else if (FP8 && st == ST3) P_W(S, ST3);                                                                 \
+        else P_W(S, 0);                                                                                         \
+    } while (0)
+            if (steps <= 0) P_WS(0);
+            else if (steps == 1) P_WS(1);
+            else P_WS(2);
+#undef P_WS
+#undef P_W
+            return;
+        }
         if (younger >= AH) {
             if (xkt < NS - 1 && pend == ST1) { if (a2) wait_vm<OPS_HI * AH + ST1>(); else wait_vm<OPS_LO * AH + ST1>(); }
             else if (xkt < NS - 1 && pend == ST2) { if (a2) wait_vm<OPS_HI * AH + ST2>(); else wait_vm<OPS_LO * AH + ST2>(); }
@@ -240,14 +277,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
         }
+        const bool prev = EI && ord > 0;
         if (PP && wr == 1) {                             // row 1 falls one barrier epoch behind row 0
-            wait_step(0, cs);
+            wait_step(0, cs, prev);
             __builtin_amdgcn_s_barrier();
         }
         for (int kt = 0; kt < nk; ++kt, ++cs) {
-            if (!PP || wr == 0) wait_step(kt, cs);
+            if (!PP || wr == 0) wait_step(kt, cs, prev);
             __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done reading step cs - 1
-            issue_one();                                 // step cs + NS - 1 refills the stage step cs - 1 occupied
+            if (!(prev && kt == 0)) issue_one();         // step cs + NS - 1 refills the stage step cs - 1 occupied (EI: issued at the last tile's end)
             const char* st = smem + (cs % NS) * STAGE;
             if constexpr (K64) {
                 // two 64-byte sub-steps (32 bf16 / 64 e4m3 deep), each a read epoch and a matrix epoch; row 1 runs one epoch behind row 0
@@ -261,8 +299,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
 #pragma unroll
                     for (int i = 0; i < NI; ++i) fa[i] = *(const frag_t*)(st + (oa[i] ^ (h * 64)));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (h == 1 && wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1);
+                    if (h == 1 && wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1, prev);
                     __builtin_amdgcn_s_barrier();
+                    // EI: the tile's last stage has now been read by every wave: the next tile's step NS - 1 goes out ahead of the stores
+                    if (EI && h == 1 && wr == 1 && kt == nk - 1) issue_one();
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -286,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             auto pp_mid = [&]() {
                 if constexpr (PP) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1);
+                    if (wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1, prev);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -343,7 +383,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 __builtin_amdgcn_s_setprio(0);
             }
         }
-        if (PP && wr == 0) __builtin_amdgcn_s_barrier();      // pairs with row 1's last hand-over: the rows meet again at the epilogue
+        if (PP && wr == 0) {
+            __builtin_amdgcn_s_barrier();               // pairs with row 1's last hand-over: the rows meet again at the epilogue
+            if (EI) issue_one();
+        }
 
         // ---- epilogue, straight from the accumulators:  acc[i][j][r] = C[m0 + wr*WM + i*16 + fr][n0 + wc*64 + j*16 + 4*fg + r]
         int m0, n0;
@@ -355,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         float b4[4][4];
         if (g.bias) {
             // inline asm: a ds_read hipcc can see makes it drain the LDS-DMA queue first (s_waitcnt vmcnt(0) in front of every read)
-            const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + BIAS_OFF + (ord & 1) * 1024 + (wc * 64 + 4 * fg) * 4);
+            const unsigned ba = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + BIAS_OFF + (ord % NBS) * 1024 + (wc * 64 + 4 * fg) * 4);
             f32x4_t t0, t1, t2, t3;
             asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
                          "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
@@ -506,6 +549,23 @@ extern "C" int mvuld_set_gemm_p256_k64(int on) {
     return 0;
 }
 
+// early issue of the next tile's step ahead of the epilogue's stores (template parameter EI; bf16 full-line ring): MVULD_P256_EARLY,
+// mvuld_set_gemm_p256_early (tests, A/B timing).  Bit-identical results.
+static std::atomic<int> g_p256_early{-1};
+static bool p256_early() {
+    int v = g_p256_early.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_P256_EARLY");
+        v = e ? (atoi(e) != 0) : P256_EARLY_DEFAULT;
+        g_p256_early.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mvuld_set_gemm_p256_early(int on) {
+    g_p256_early.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
 template <int EPI, int NI>
 static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int tiles_m = (int)cdiv(g.M, 32 * NI);
@@ -513,6 +573,16 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
     if (p256_k64() && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb * 2 < ((int64_t)1 << 32)) {
         constexpr int NS6 = NI <= 5 ? 3 : 2;
+        if (p256_early()) {
+            constexpr int LDSE = NS6 * (NI * 4096 + 32768) + 3072;
+            static const bool attre = [] {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSE);
+                return true;
+            }();
+            (void)attre;
+            hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, true>), dim3(grid), dim3(512), LDSE, stream, g, tiles_m, tiles_n);
+            return;
+        }
         if constexpr (NI <= 5) {
             // MVULD_P256_K64_NS2=1: two stages below 192 rows too (A/B of the ring depth on one tile shape)
             static const bool two = [] { const char* e = getenv("MVULD_P256_K64_NS2"); return e && atoi(e) != 0; }();

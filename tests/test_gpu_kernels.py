@@ -128,6 +128,7 @@ def _gemm_large_ragged(gpu, K):
 
 
 K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "1"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
+EARLY_DEFAULT = int(os.environ.get("MVULD_P256_EARLY", "0"))  # ... and P256_EARLY_DEFAULT
 
 
 @pytest.mark.parametrize("M,N,K,rows", [(6401, 2056, 544, 0), (6401, 2056, 544, 128), (6401, 2056, 544, 160), (6401, 2056, 544, 192),
@@ -152,6 +153,7 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     hip.LIB.fn("mvuld_set_gemm_p256_rows")(rows)       # tile height: 0 = chosen per shape, else forced
     pp = hip.LIB.fn("mvuld_set_gemm_p256_pingpong")
     k64 = hip.LIB.fn("mvuld_set_gemm_p256_k64")
+    early = hip.LIB.fn("mvuld_set_gemm_p256_early")
     k64(0)
 
     def both(**kw):
@@ -170,12 +172,16 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         if K % 64 == 0:
             # 64-deep full-line ring stages (two or three stages, two 32-deep sub-steps each): the same contraction order again
             k64(1)
-            o2 = ops.gemm_nt(A, B_, **kw)
-            o3 = ops.gemm_nt(A, B_, **kw)
+            for e in (0, 1, 1):
+                # early = 1: the next tile's prefetched step goes out ahead of the epilogue's stores (three bias slices, the DMA stream up
+                # to two tiles ahead of the epilogue at K = 128)
+                early(e)
+                o2 = ops.gemm_nt(A, B_, **kw)
+                assert torch.equal(o2, o1)
+                if a1 is not None:
+                    assert torch.equal(a1, kw["aux"])
+            early(EARLY_DEFAULT)
             k64(0)
-            assert torch.equal(o2, o1) and torch.equal(o3, o1)
-            if a1 is not None:
-                assert torch.equal(a1, kw["aux"])
         return o1
     try:
         out = both()
@@ -204,6 +210,7 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
         pp(1)
         k64(K64_DEFAULT)
+        early(EARLY_DEFAULT)
 
 
 @pytest.mark.parametrize("M,N,K", [(6401, 2056, 544), (20000, 1288, 160), (70000, 512, 128), (769, 520, 1024), (25088, 2048, 512), (300, 2048, 256),
