@@ -83,9 +83,9 @@ int mvuld_fp8_roll_scales(float* state, int n, mvuld_stream_t stream);
 /* CUs the 256x256 weight-gradient kernel plans its contraction splits for: 0 = all (best alone); the fused training step sets half
  * the chip while its streams run concurrently (a smaller footprint beside the data-gradient chain: step -1 %) */
 int mvuld_set_gemm_tn256_budget(int cus);
-/* Schedule of the 256x256 weight-gradient kernel's main loop: 0 (default) = lockstep, 1 = ping-pong (the two waves of a SIMD half a slab
- * step apart: one reads its transposed fragments while the other owns the matrix pipe; measured 1 % slower here, kept for A/B runs).
- * Bit-identical weight gradients; MVULD_TN256_PINGPONG. */
+/* Schedule of the 256x256 weight-gradient kernel's main loop: 1 (default) = ping-pong (the two waves of a SIMD half a slab step apart:
+ * one reads its transposed fragments while the other owns the matrix pipe), 0 = lockstep.  Bit-identical weight gradients;
+ * MVULD_TN256_PINGPONG. */
 int mvuld_set_gemm_tn256_pingpong(int on);
 int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),

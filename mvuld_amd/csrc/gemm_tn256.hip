@@ -22,6 +22,9 @@
 
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
 
+#ifndef TN256_X
+#define TN256_X 0      // timing experiments (tools/tn256_variants.sh; results are WRONG): bit 0 = fragments read once (no LDS reads in the loop),
+#endif                 // bit 1 = no DMA after the first three slabs, bit 2 = no partial-slab / output stores
 #define T_STAGE_BYTES 32768            // dY [32][256] bf16 (16 KiB) + X [32][256] bf16 (16 KiB)
 #define T_LDS_BYTES (4 * T_STAGE_BYTES)
 #define T_SLAB_FLOATS 65536            // one 256 x 256 fp32 partial
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
     const unsigned stepa = (unsigned)(64 * ldy), stepb = (unsigned)(64 * ldx);      // bytes per 32-row slab
     int issued = 0;
     auto issue_one = [&]() {
+        if ((TN256_X & 2) && issued >= 3) return;
         if (issued < nk) {
             char* st = smem + (issued & 3) * T_STAGE_BYTES;
 #pragma unroll
@@ -117,23 +121,48 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
         wait_slab(0);
         __builtin_amdgcn_s_barrier();
     }
+    bf16x8_t fa[8], fb[4];
     for (int kt = 0; kt < nk; ++kt) {
         if (!PP || wr == 0) wait_slab(kt);
         __builtin_amdgcn_s_barrier();                    // slab kt visible to every wave; every wave is done with slab kt - 1
         issue_one();                                     // slab kt + 3 refills the stage slab kt - 1 occupied
         const char* st = smem + (kt & 3) * T_STAGE_BYTES;
-        bf16x8_t fa[8], fb[4];
+        if (!(TN256_X & 1) || kt == 0) {
+        // The transposed reads are inline asm: through the builtin hipcc sees LDS reads next to outstanding LDS-DMA (buffer_load ... lds) and
+        // puts `s_waitcnt vmcnt(0)` in front of the first one -- every step then waited for ALL three slabs in flight, i.e. the four-stage
+        // ring ran as a synchronous load per step (the compiled loop of rounds 1-2; found by reading the ISA).  Two blocks, each ending in
+        // its own lgkmcnt(0), so the outputs are valid registers when the statement retires.
+        {
+            const unsigned sb = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)st;
+            long bl[4], bh[4], al[8], ah[8];
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:8192\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(bl[0]), "=&v"(bh[0]), "=&v"(bl[1]), "=&v"(bh[1]), "=&v"(bl[2]), "=&v"(bh[2]), "=&v"(bl[3]), "=&v"(bh[3])
+                         : "v"(sb + ob[0]), "v"(sb + ob[1]), "v"(sb + ob[2]), "v"(sb + ob[3])
+                         : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %20 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %10, %21\n\tds_read_b64_tr_b16 %11, %21 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %12, %22\n\tds_read_b64_tr_b16 %13, %22 offset:8192\n\t"
+                         "ds_read_b64_tr_b16 %14, %23\n\tds_read_b64_tr_b16 %15, %23 offset:8192\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(al[0]), "=&v"(ah[0]), "=&v"(al[1]), "=&v"(ah[1]), "=&v"(al[2]), "=&v"(ah[2]), "=&v"(al[3]), "=&v"(ah[3]),
+                           "=&v"(al[4]), "=&v"(ah[4]), "=&v"(al[5]), "=&v"(ah[5]), "=&v"(al[6]), "=&v"(ah[6]), "=&v"(al[7]), "=&v"(ah[7])
+                         : "v"(sb + oa[0]), "v"(sb + oa[1]), "v"(sb + oa[2]), "v"(sb + oa[3]), "v"(sb + oa[4]), "v"(sb + oa[5]), "v"(sb + oa[6]),
+                           "v"(sb + oa[7])
+                         : "memory");
+            typedef long __attribute__((ext_vector_type(2))) t_i64x2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + ob[j]));
-            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + ob[j] + 16 * 512));
-            fb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int j = 0; j < 4; ++j) fb[j] = __builtin_bit_cast(bf16x8_t, (t_i64x2){bl[j], bh[j]});
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = __builtin_bit_cast(bf16x8_t, (t_i64x2){al[i], ah[i]});
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + oa[i]));
-            const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(st + oa[i] + 16 * 512));
-            fa[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
         if constexpr (PP) {
             // the fragments are in registers before the barrier that hands the matrix pipe over (and the stage back to the DMA)
@@ -172,7 +201,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4_t*)(mine + ((wave * 32 + i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+            for (int j = 0; j < 4; ++j) {
+                if (TN256_X & 4) asm volatile("" ::"v"(acc[i][j]));
+                else *(f32x4_t*)(mine + ((wave * 32 + i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+            }
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -230,15 +262,16 @@ static int tn256_num_cus() {
     return b > 0 && b < tn256_all_cus() ? b : tn256_all_cus();
 }
 
-// schedule of the main loop: 0 (default) = lockstep, 1 = ping-pong; MVULD_TN256_PINGPONG, mvuld_set_gemm_tn256_pingpong (tests, A/B timing).
-// Measured (tools/gemm_shapes.py --only tn, same box): ping-pong 12.25 ms per step's worth against 12.13 ms in lockstep (+1 %, +2..3 % on the
-// long-contraction shapes) -- unlike the NT kernel this loop does not lose its time to the read / MFMA alternation, so the extra barrier only costs.
+// schedule of the main loop: 1 (default) = ping-pong, 0 = lockstep; MVULD_TN256_PINGPONG, mvuld_set_gemm_tn256_pingpong (tests, A/B timing).
+// Measured (tools/gemm_shapes.py --only tn, same box): while hipcc's `s_waitcnt vmcnt(0)` in front of the builtin transposed reads made every
+// step a synchronous load, ping-pong was 1 % slower (12.25 vs 12.13 ms per step's worth); with the reads in inline asm the ring really runs
+// three slabs ahead (10.77 ms) and the read / MFMA alternation is what is left to hide: 10.40 ms with ping-pong.
 static std::atomic<int> g_tn256_pp{-1};
 static bool tn256_pingpong() {
     int v = g_tn256_pp.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("MVULD_TN256_PINGPONG");
-        v = e ? (atoi(e) != 0) : 0;
+        v = e ? (atoi(e) != 0) : 1;
         g_tn256_pp.store(v, std::memory_order_relaxed);
     }
     return v != 0;

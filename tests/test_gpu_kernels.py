@@ -870,7 +870,7 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         assert rel(b.grad, 3.0 * dy.sum(0) + 1.0) < 2e-3
         tn, tk = -(-N // 256), -(-K // 256)
         if mode == "tn256" and M >= 256 and tn * tk >= 8 and tn * tk * 65536 * 4 <= N * K * 5:      # tn256_plan(): the kernel takes these
-            # ping-pong and lockstep (default) schedules of the 256 x 256 kernel contract in the same order: equal weight gradients, and
+            # ping-pong (default) and lockstep schedules of the 256 x 256 kernel contract in the same order: equal weight gradients, and
             # equal again on a repeated launch (a mis-placed wait reads a slab before its DMA has landed); the bias gradient is fp32
             # atomics from the splits, equal up to their order
             res = []
@@ -885,7 +885,7 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
     finally:
         ops.USE_TN_SLABS[0] = True
         hip.LIB.fn("mvuld_set_gemm_tn256")(1)
-        hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(0)
+        hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(1)
 
 
 @pytest.mark.parametrize("B,h,w,S", [(2, 600, 800, 448), (1, 300, 200, 448), (3, 448, 448, 448), (1, 1000, 448, 448), (2, 97, 1301, 448),
