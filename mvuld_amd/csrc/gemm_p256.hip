@@ -27,6 +27,9 @@
 #ifndef P256_K64_DEFAULT
 #define P256_K64_DEFAULT 1
 #endif
+#ifndef P256_TWO_PASS
+#define P256_TWO_PASS 0      // 1: two-pass dGELU / residual-join epilogue (see the epilogue; measured: spills at 224 / 256-row tiles, so off)
+#endif
 #ifndef P256_EARLY_DEFAULT
 #define P256_EARLY_DEFAULT 0
 #endif
@@ -422,10 +425,46 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 z[i][jp] = *(const uint4*)(aux + (int64_t)rowc * g.ldaux + (col < g.N ? col : 0));
             }
         };
+        // AUX_IN epilogues in TWO passes (P256_TWO_PASS): first the aux operand is folded into the accumulators, in place, while nothing but
+        // loads is in flight; then everything is packed and stored.  In one pass every aux fetch sat behind the stores of the rows before it,
+        // and hipcc cannot count stores that sit behind the `row < M && col < N` branch: it assumed none had been issued and emitted
+        // `s_waitcnt vmcnt(1)`, `vmcnt(0)` in front of the last rows' aux values -- the wave waited for (nearly) all of its own stores to be
+        // acknowledged before it could finish the tile (ISA of the dGELU / residual-join variants).
+        // Built with -DP256_TWO_PASS=1 the waits come out as intended (counted, loads only), but the second copy of the row loop costs ~12
+        // registers: 256 VGPRs + 9 (224 rows) / 68 (256 rows) spilled, and the spill reloads are scratch loads, i.e. vmcnt(0) again.  Off
+        // until the epilogue is cut differently (round-3 item: an interior-tile epilogue with unconditional stores lets hipcc count them).
+        constexpr bool TWO_PASS = AUX_IN && (P256_TWO_PASS != 0);
         if (AUX_IN) { load_aux(0); load_aux(1); }
+        if constexpr (TWO_PASS) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (i + 2 < NI) load_aux(i + 2);
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int j0 = 2 * jp;
+                    const uint4 zz = z[i][jp];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(zz.x, zz.z, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(zz.y, zz.w, false, false);
+                    float x[2][4];
+                    x[0][0] = bf_lo(s0[0]); x[0][1] = bf_hi(s0[0]); x[0][2] = bf_lo(s1[0]); x[0][3] = bf_hi(s1[0]);
+                    x[1][0] = bf_lo(s0[1]); x[1][1] = bf_hi(s0[1]); x[1][2] = bf_lo(s1[1]); x[1][3] = bf_hi(s1[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
+                            if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
+                            else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
+                            else if (EPI == EPI_ADD_AUX) t += x[h][r];
+                            acc[i][j0 + h][r] = t;
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // keep the fetches two rows ahead: hoisted to the front they are 56 live registers more
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (AUX_IN && i + 2 < NI) load_aux(i + 2);
+            if (AUX_IN && !TWO_PASS && i + 2 < NI) load_aux(i + 2);
             const int row = mw + i * 16 + fr;
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
@@ -434,7 +473,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 const int col = nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8;
                 const bool ok = (P256_X & 1) ? false : (row < g.M && col < g.N);
                 float x[2][4];
-                if (AUX_IN) {
+                if (AUX_IN && !TWO_PASS) {
                     const uint4 zz = z[i][jp];
                     const auto s0 = __builtin_amdgcn_permlane16_swap(zz.x, zz.z, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(zz.y, zz.w, false, false);
@@ -446,9 +485,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float t = alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
+                        float t = TWO_PASS ? acc[i][j0 + h][r] : alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
                         pre[h][r] = t;
-                        if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
+                        if (TWO_PASS) {}
+                        else if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
                         else if (EPI == EPI_GELU) t = gelu_fast(t);
                         else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
                         else if (EPI == EPI_ADD_AUX) t += x[h][r];
