@@ -289,9 +289,14 @@ static void tn256_plan(int M, int N, int K, int& nsplit, int& per) {
     const int64_t tiles = cdiv(N, 256) * cdiv(K, 256);
     // fewer than 8 tiles would mean > 32 splits: the partial slabs (256 KiB each) then cost more than the 128 x 128 kernel's atomics
     // (measured, tools/gemm_shapes.py: 512 x 512 and 256 x 256 weights lose, 768 x 768 breaks even, everything wider wins 15-25 %)
-    if (tiles < 8) return;
-    // most of every tile must be real weight: (padded area) <= 1.25 x (N x K)
-    if (cdiv(N, 256) * 256 * cdiv(K, 256) * 256 * 4 > (int64_t)N * K * 5) return;
+    static const int min_tiles = [] { const char* e = getenv("MVULD_TN256_MIN_TILES"); const int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    static const int max_pad4 = [] { const char* e = getenv("MVULD_TN256_MAX_PAD4"); const int v = e ? atoi(e) : 5; return v >= 4 ? v : 5; }();
+    // ... except where the contraction is very long: with the ring running asynchronously (reads in inline asm) the 3- and 4-tile weights of
+    // Swin stage 1 (100 352 tokens; 1024 x 256: 114 -> 80 us, 256 x 1024: 114 -> 89 us, 768 x 256: 91 -> 83 us) win too; 2-tile weights and
+    // the 4-tile 512 x 512 at 25 088 tokens still lose (tools/gemm_shapes.py --only tn with MVULD_TN256_MIN_TILES = 1 / 2 / 4)
+    if (tiles < min_tiles && !(min_tiles == 8 && tiles >= 3 && M >= 65536)) return;
+    // most of every tile must be real weight: (padded area) <= 1.25 x (N x K)   (MVULD_TN256_MAX_PAD4 / 4: A/B runs)
+    if (cdiv(N, 256) * 256 * cdiv(K, 256) * 256 * 4 > (int64_t)N * K * max_pad4) return;
     const int mslabs = (M + 31) / 32;
     int want = (int)(tn256_num_cus() / tiles);
     if (want < 1) want = 1;

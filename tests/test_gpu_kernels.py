@@ -843,7 +843,8 @@ def test_embed_im2col_patchmerge_dropout(gpu, dtype):
 
 @pytest.mark.parametrize("mode", ["tn256", "slab128", "atomic"])
 @pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (1000, 384, 136), (777, 72, 200), (20000, 256, 512), (16384, 776, 392),
-                                   (16384, 768, 768), (6272, 1000, 760), (25088, 512, 2048), (2048, 256, 256), (9917, 768, 3072), (1001, 1024, 520)])
+                                   (16384, 768, 768), (6272, 1000, 760), (25088, 512, 2048), (2048, 256, 256), (9917, 768, 3072), (1001, 1024, 520),
+                                   (70000, 1024, 256), (66001, 768, 256)])
 def test_gemm_tn_wgrad(gpu, M, N, K, mode):
     """dW += dY^T X and db += colsum(dY) through the transpose-free matrix-core kernels (bf16 operands).  Three ways of combining the
     split token contraction: "tn256" = the 256 x 256-tile LDS-DMA kernel with slab partials + reduction launch where the shape
@@ -869,7 +870,8 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         assert rel(w.grad, 3.0 * ref + 1.0) < 2e-3
         assert rel(b.grad, 3.0 * dy.sum(0) + 1.0) < 2e-3
         tn, tk = -(-N // 256), -(-K // 256)
-        if mode == "tn256" and M >= 256 and tn * tk >= 8 and tn * tk * 65536 * 4 <= N * K * 5:      # tn256_plan(): the kernel takes these
+        enough = tn * tk >= 8 or (tn * tk >= 3 and M >= 65536)       # (3- and 4-tile weights only with a very long contraction)
+        if mode == "tn256" and M >= 256 and enough and tn * tk * 65536 * 4 <= N * K * 5:      # tn256_plan(): the kernel takes these
             # ping-pong (default) and lockstep schedules of the 256 x 256 kernel contract in the same order: equal weight gradients, and
             # equal again on a repeated launch (a mis-placed wait reads a slab before its DMA has landed); the bias gradient is fp32
             # atomics from the splits, equal up to their order
