@@ -30,7 +30,10 @@ class GraphedTrainStep:
         ops.RNG_OFFSET[0] = self.counter
         ng = len(optimizer.param_groups)
         optimizer.dev_hyper = torch.zeros((ng, 3), dtype=torch.float32, device=dev)
+        # staging ring for {lr, bias corrections}: a slot is rewritten only after the copy that last read it has run (its event);
+        # a replay costs microseconds on the host and tens of ms on the GPU, so nothing else throttles an unsynchronised step() loop
         self._pinned = [torch.empty((ng, 3), dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._pinned_ev = [None] * len(self._pinned)
         if hasattr(model, "max_steps_in_flight"):
             model.max_steps_in_flight = 0
         # warm-up on a side stream: allocator pools, workspaces, transposed-weight job tables, LDS attribute calls ... all exist
@@ -64,9 +67,15 @@ class GraphedTrainStep:
 
     def _upload_hyper(self):
         self.sched.step_update(self.it)                          # sets param_group["lr"] for this iteration (cosine, per iteration)
-        buf = self._pinned[self.it % len(self._pinned)]
+        slot = self.it % len(self._pinned)
+        buf = self._pinned[slot]
+        if self._pinned_ev[slot] is not None:
+            self._pinned_ev[slot].synchronize()                   # the H2D copy queued len(ring) steps ago has consumed this slot
         buf.copy_(self.opt.host_hyper())
         self.opt.dev_hyper.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.labels.device))
+        self._pinned_ev[slot] = ev
 
     def step(self):
         """One training step = one graph launch.  Returns the (device) loss and gradient-norm tensors of that step."""

@@ -970,8 +970,10 @@ def test_swin_finetune_driver_cli(gpu, tmp_path):
 def test_graphed_train_step_matches_eager(gpu):
     """The hipGraph-captured training step (graph_step.GraphedTrainStep: forward, CE, backward on the three streams, clip, fused AdamW
     with learning rate / bias corrections read from device memory, RNG step counter advanced inside the graph) against the same
-    steps enqueued from Python: same model, same data, same cosine schedule, dropouts off -> the parameters after 4 steps must agree
-    to fp32-atomic-order noise, and the loss sequence must match."""
+    steps enqueued from Python: same model, same data, same cosine schedule, dropouts off -> the parameters after 9 steps must agree
+    to fp32-atomic-order noise, and the loss sequence must match.  The replays are issued WITHOUT a host synchronisation in between
+    (more of them than the {lr, bias-correction} staging ring has slots): a slot overwritten before its copy ran would hand earlier
+    replays the learning rate of later steps."""
     from mvuld_amd.data import synthetic
     from mvuld_amd.graph_step import GraphedTrainStep
     from mvuld_amd.lr_scheduler import build_scheduler
@@ -994,7 +996,7 @@ def test_graphed_train_step_matches_eager(gpu):
         m.head.gat.feat_drop_p = m.head.gat2.feat_drop_p = 0.0
         o = build_optimizer(config, m)
         return m, o, build_scheduler(config, o, 10)
-    n_steps = 3 + 4                          # GraphedTrainStep runs 3 eager warm-up steps before capturing
+    n_steps = 3 + 9                          # GraphedTrainStep runs 3 eager warm-up steps before capturing
     m1, o1, s1 = make()
     losses_e = []
     for it in range(n_steps):
@@ -1011,9 +1013,10 @@ def test_graphed_train_step_matches_eager(gpu):
     gs = GraphedTrainStep(m2, o2, s2, cross_entropy, (g, images, ids), labels, config.TRAIN.CLIP_GRAD,
                           model_kwargs={"seq_lens": RobertaModel.pack_plan(lens, gpu, ids.shape[1])})
     losses_g = []
-    for _ in range(4):
+    for _ in range(9):
         loss, norm = gs.step()
-        losses_g.append(float(loss))
+        losses_g.append(loss.detach().clone())          # device-side copy on the replay stream: no host sync between replays
+    losses_g = [float(x) for x in losses_g]
     gs.close()
     assert o2._step == o1._step == n_steps
     print("eager losses", losses_e[3:], "graph losses", losses_g)

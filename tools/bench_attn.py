@@ -7,7 +7,8 @@ from mvuld_amd import ops, hip
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", 32))
 cases = [("swin s0", 0, 4, 32, 112, 28, 14), ("swin s0 noshift", 0, 4, 32, 112, 28, 0), ("swin s1", 0, 8, 32, 56, 28, 14),
-         ("swin s2", 0, 16, 32, 28, 28, 0), ("swin s3", 0, 32, 32, 14, 14, 0), ("roberta", 1, 12, 64, 0, 0, 0)]
+         ("swin s2", 0, 16, 32, 28, 28, 0), ("swin s3", 0, 32, 32, 14, 14, 0), ("roberta", 1, 12, 64, 0, 0, 0),
+         ("roberta packed", 2, 12, 64, 0, 0, 0), ("roberta packed drop", 2, 12, 64, 0, 0, 0)]
 which = sys.argv[1:] or ["auto"]
 only = os.environ.get("CASES")
 for name, mode, H, hd, res, ws, shift in cases:
@@ -22,12 +23,18 @@ for name, mode, H, hd, res, ws, shift in cases:
         table = torch.rand(T2, H, device=dev) * 16
         ls = torch.full((H,), 2.3, device=dev)
         valid = None
-    else:
+    elif mode == 1:
         N, nW = 512, 1
         tokens = B * N
         g = ops.AttnGeom(1, B, H, hd, N, 1, 0, 0, 0, 1 / math.sqrt(hd))
         table = ls = None
         valid = torch.ones(B, N, dtype=torch.int32, device=dev)
+    else:                       # the fused step's text encoder: packed full rows (cu_seqlens), attention dropout 0.1 in training
+        N, nW = 512, 1
+        tokens = B * N
+        g = ops.AttnGeom(2, B, H, hd, N, 1, tokens, 0, 0, 1 / math.sqrt(hd), sumsq=B * N * N, drop_p=0.1 if "drop" in name else 0.0, drop_seed=1234)
+        table = ls = None
+        valid = torch.arange(0, B + 1, dtype=torch.int32, device=dev) * N
     qkv = torch.randn(tokens, 3 * C, device=dev).to(torch.bfloat16)
     dout = torch.randn(tokens, C, device=dev).to(torch.bfloat16)
     pairs = B * nW * H * N * N
@@ -40,7 +47,7 @@ for name, mode, H, hd, res, ws, shift in cases:
             dq = ops.attn_bwd(g, qkv, out, dout, lse, table, ls, valid, dtab, dls)
         torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        it = 5
+        it = int(os.environ.get('IT', 5))
         e[0].record()
         for _ in range(it):
             out, lse = ops.attn_fwd(g, qkv, table, ls, valid)
