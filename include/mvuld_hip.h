@@ -182,6 +182,12 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
  * on 256), the groups of the partial last round are split over 2..4 workgroups each so that it fills up (results are bit-identical:
  * a query / key tile is computed by one wave either way).  1 = on, 0 = off (default; MVULD_ATTN_TAIL_SPLIT) -- measured neutral */
 int mvuld_set_attn_tail_split(int on);
+/* mode 0, head_dim 32, window side a multiple of 4 (the SwinV2 stages with 28 x 28 windows): the FORWARD pass runs on the window fast
+ * path (three shifted copies of the bias table read with aligned 8-byte LDS reads, two query tiles per wave).  1 (default) = with the
+ * deferred softmax maximum (the running maximum of a query moves only when a block exceeds it by 2^6; out / lse equal the general
+ * kernel's to bf16 rounding), 2 = on the general kernel's exact schedule (bit-identical to it), 0 = the general kernel
+ * (MVULD_ATTN_WIN). */
+int mvuld_set_attn_win(int mode);
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
  * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).

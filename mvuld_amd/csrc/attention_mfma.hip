@@ -1118,6 +1118,271 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     }
 }
 
+// ================================================================================================ window fast path (round 3)
+// MODE 0, head_dim 32, window side a multiple of 4 (SwinV2-base stages 0-2: 28 x 28 windows).  Same arithmetic, same block sizes and
+// the same accumulation order as the kernels above -- outputs are BIT-IDENTICAL (tests compare the two) -- but the passes were bound by
+// the LDS (profiles/r03_base_attn_counters.csv: LDS array busy 0.50-0.80 of the CU's cycles, 37-40 % of that bank conflicts), so the LDS
+// work per score is cut:
+//   * bias words: the table is kept THREE times, copy c shifted by c words, S3 bytes apart.  A table word index w is encoded as
+//     8 * (w >> 1) + (w & 1) * S3; the sum of a query-side and a key-side encoding then addresses copy (parity + parity) at an 8-byte
+//     aligned word pair -- the carry of the two parities lands in the copy index instead of breaking the alignment -- so a lane's four
+//     adjacent words are two ds_read_b64 (2 LDS cycles each, 64 banks) instead of two ds_read2_b32 (4 cycles each, 32 banks), with
+//     one v_add for the address as before.  S3 / 4 = 22 mod 64 keeps the copies' bank ranges apart.
+//   * the encoded offsets of a block's key groups are one 16-byte read per lane (Koff[block][fg][tile]) instead of four info words;
+//   * all bias reads of a block are issued back to back in ONE asm statement behind one wait (the compiled loops above hold one
+//     lgkmcnt(0) per tile: DESIGN section 9b item 6);
+//   * forward: two query tiles per wave share every K fragment, transposed V read and offset word (as the dQ pass already did);
+//     dK/dV: two key tiles per wave share the Q~ / dO fragments, their transposed reads and the per-query lse / delta / offset words.
+typedef __attribute__((address_space(3))) char* lds_cp;
+__device__ __forceinline__ unsigned aw_lds(const void* p) { return (unsigned)(uintptr_t)(lds_cp)(char*)p; }
+__host__ __device__ inline int aw_stride_bytes(int T2) {
+    int s = (T2 + 3) / 2 * 2;            // words: room for the copy shifted by two, even
+    while ((s & 63) != 22) s += 2;
+    return s * 4;
+}
+__device__ __forceinline__ int aw_enc(int w, int S3) { return ((w >> 1) << 3) + (w & 1) * S3; }
+
+// three shifted copies of the head's table in log2 units; REV: entry i holds table[T2 - 1 - i] (forward / dQ: keys on the rows)
+template <bool REV>
+__device__ __forceinline__ void aw_fill_table(float* tab3, const float* __restrict__ table16, int T2, int H, int h, int S3) {
+    const int W = S3 >> 2;
+    for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) {
+        const int c = i / W, j = i - c * W + c;
+        tab3[i] = j < T2 ? table16[(int64_t)(REV ? T2 - 1 - j : j) * H + h] * LOG2E : 0.f;
+    }
+}
+// Koff[blk][fg][t] = encoded table offset of window position blk*64 + 16 t + 4 fg (positions >= N: 0, a safe in-range read)
+__device__ __forceinline__ void aw_fill_off(int* Koff, int nblk, int N, int ws, int S3) {
+    const int W2 = 2 * ws - 1;
+    for (int i = threadIdx.x; i < nblk * 16; i += blockDim.x) {
+        const int n = (i >> 4) * 64 + (i & 3) * 16 + ((i >> 2) & 3) * 4;
+        Koff[i] = n < N ? aw_enc((n / ws) * W2 + n % ws, S3) : 0;
+    }
+}
+
+// bias words of NB (tile, tile) pairs: per pair two 8-byte reads, all issued back to back, one wait; outputs valid on return
+__device__ __forceinline__ void aw_bias_read(const unsigned (&a)[2], f32x4_t (&b)[2]) {
+    f32x2_t l0, h0, l1, h1;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %5\n\tds_read_b64 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1) : "v"(a[0]), "v"(a[1]) : "memory");
+    b[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3);
+    b[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void aw_bias_read(const unsigned (&a)[4], f32x4_t (&b)[4]) {
+    f32x2_t l0, h0, l1, h1, l2, h2, l3, h3;
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %9\n\tds_read_b64 %3, %9 offset:8\n\t"
+                 "ds_read_b64 %4, %10\n\tds_read_b64 %5, %10 offset:8\n\tds_read_b64 %6, %11\n\tds_read_b64 %7, %11 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+    b[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3);
+    b[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3);
+    b[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3);
+    b[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void aw_bias_read(const unsigned (&a)[8], f32x4_t (&b)[8]) {
+    f32x2_t l[8], h[8];
+    asm volatile("ds_read_b64 %0, %16\n\tds_read_b64 %1, %16 offset:8\n\tds_read_b64 %2, %17\n\tds_read_b64 %3, %17 offset:8\n\t"
+                 "ds_read_b64 %4, %18\n\tds_read_b64 %5, %18 offset:8\n\tds_read_b64 %6, %19\n\tds_read_b64 %7, %19 offset:8\n\t"
+                 "ds_read_b64 %8, %20\n\tds_read_b64 %9, %20 offset:8\n\tds_read_b64 %10, %21\n\tds_read_b64 %11, %21 offset:8\n\t"
+                 "ds_read_b64 %12, %22\n\tds_read_b64 %13, %22 offset:8\n\tds_read_b64 %14, %23\n\tds_read_b64 %15, %23 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3]),
+                   "=&v"(l[4]), "=&v"(h[4]), "=&v"(l[5]), "=&v"(h[5]), "=&v"(l[6]), "=&v"(h[6]), "=&v"(l[7]), "=&v"(h[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = __builtin_shufflevector(l[i], h[i], 0, 1, 2, 3);
+}
+
+// encoded offsets of the NT key (query) groups of the block at position kb: Koff[kb / 64][fg][t], NT = 2 takes half of the 16-byte row
+template <int NT>
+__device__ __forceinline__ void aw_load_off(const int* __restrict__ Koff, int kb, int fg, int (&ko)[NT]) {
+    if constexpr (NT == 4) {
+        const int4 v = *(const int4*)(Koff + (kb >> 6) * 16 + fg * 4);
+        ko[0] = v.x; ko[1] = v.y; ko[2] = v.z; ko[3] = v.w;
+    } else {
+        const int2 v = *(const int2*)(Koff + (kb >> 6) * 16 + fg * 4 + ((kb >> 5) & 1) * 2);
+        ko[0] = v.x; ko[1] = v.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, two query tiles per wave
+#define AW_LAZY_TH 6.0f
+template <bool MASK, bool TAIL, int NT, int QT, bool LAZY>
+__device__ __forceinline__ void aw_fwd_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo,
+                                             const int* __restrict__ Koff, int kb, const bf16x8_t (&qf)[QT], const unsigned (&tabq)[QT],
+                                             const int (&regq)[QT], int lane, float (&m)[QT], f32x4_t (&lacc)[QT], f32x4_t (&oacc)[QT][2],
+                                             const bf16x8_t& ones) {
+    const int fc = lane & 15, fg = lane >> 4;
+    int ko[NT];
+    aw_load_off<NT>(Koff, kb, fg, ko);
+    unsigned a[QT * NT];
+    f32x4_t s[QT * NT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[q * NT + t] = tabq[q] + (unsigned)ko[t];
+    aw_bias_read(a, s);
+    int ki[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (MASK || TAIL) {
+            const int4 inf = *(const int4*)(Kinfo + kb + 16 * t + 4 * fg);
+            ki[t][0] = inf.x; ki[t][1] = inf.y; ki[t][2] = inf.z; ki[t][3] = inf.w;
+        }
+        const bf16x8_t kfr = *(const bf16x8_t*)(Ks + am_off<32, true>(kb + 16 * t + fc, fg));
+#pragma unroll
+        for (int q = 0; q < QT; ++q) s[q * NT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[q], s[q * NT + t], 0, 0, 0);
+    }
+    bf16x8_t pb[QT][NT / 2];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+        float bm = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MASK || TAIL) s[q * NT + t][r] = am_mask<0, MASK, TAIL>(s[q * NT + t][r], ki[t][r], regq[q], 0);
+                bm = fmaxf(bm, s[q * NT + t][r]);
+            }
+        if (LAZY) {
+            // Deferred maximum: the reference point m of a query moves only when some score of the block exceeds it by more than
+            // 2^AW_LAZY_TH (wave-uniform test on the lanes' own maxima); until then p = 2^(s - m) <= 2^AW_LAZY_TH needs no cross-lane
+            // reduction and the accumulators no rescale (the passes are bound by instruction issue: profiles/r03_win_attn_counters.csv).
+            if (__builtin_amdgcn_ballot_w64(bm > m[q] + AW_LAZY_TH) != 0) {
+                const float mn = fmaxf(m[q], max4g(bm));
+                const float alpha = __builtin_amdgcn_exp2f(m[q] - mn);
+                m[q] = mn;
+                lacc[q] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) oacc[q][d] *= alpha;
+            }
+        } else {
+            const float mn = fmaxf(m[q], max4g(bm));
+            const float alpha = __builtin_amdgcn_exp2f(m[q] - mn);
+            m[q] = mn;
+            lacc[q] *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) oacc[q][d] *= alpha;
+        }
+        u32x4_t pw[NT / 2];
+        const f32x2_t mn2 = {m[q], m[q]};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp)
+                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(am_exp2((f32x2_t){s[q * NT + t][2 * hp], s[q * NT + t][2 * hp + 1]} - mn2));
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            pb[q][pr] = __builtin_bit_cast(bf16x8_t, pw[pr]);
+            lacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[q][pr], lacc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            const bf16x8_t vt = read_tr<32>(Vs, d * 16, kb + 32 * pr, lane);
+#pragma unroll
+            for (int q = 0; q < QT; ++q) oacc[q][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[q][pr], oacc[q][d], 0, 0, 0);
+        }
+}
+
+template <bool MASK, bool LAZY>
+__global__ __launch_bounds__(1024) void attn_fwd_win_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
+                                                      const float* __restrict__ logit_scale, bf16* __restrict__ out, float* __restrict__ lse,
+                                                      int Npad, int qsplit, int S3) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HD = 32, QT = 2;
+    bf16* Ks = (bf16*)smem;                       // [Npad][32] swizzled, normalised keys
+    bf16* Vs = Ks + (size_t)Npad * HD;            // [Npad][32]
+    int* Kinfo = (int*)(Vs + (size_t)Npad * HD);  // [Npad]  region ids / padding flags (masked and tail blocks only)
+    const int nblk = (Npad + 63) >> 6;
+    int* Koff = Kinfo + Npad;                     // [nblk][4][4]
+    float* tab3 = (float*)(Koff + nblk * 16);     // 3 x S3 bytes, log2 units, reversed
+    int bwh, part;
+    am_part(g, qsplit, bwh, part, qsplit);
+    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
+    const int C = g.H * HD;
+    const int64_t rs = 3 * (int64_t)C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
+    const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
+    const int Np = Npad;
+
+    stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, true, 1.0f);
+    stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) Kinfo[i] = am_info(g, nullptr, b, w, i);
+    const int W2 = 2 * g.ws - 1, T2 = W2 * W2;
+    aw_fill_off(Koff, nblk, g.N, g.ws, S3);
+    aw_fill_table<true>(tab3, table16, T2, g.H, h, S3);
+    const int C0 = T2 - 1 - ((g.ws - 1) * W2 + (g.ws - 1));
+    const float tau = __expf(fminf(logit_scale[h], LN100));
+    __syncthreads();
+
+    const int ntile = (g.N + 15) / 16, nitem = (ntile + QT - 1) / QT;
+    const int nfull64 = (g.N / 64) * 64;
+    const bool wmask = MASK && am_window_masked(g, w);
+    const unsigned tab0 = aw_lds(tab3);
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    for (int item = part + qsplit * wave; item < nitem; item += qsplit * (blockDim.x >> 6)) {
+        bool qok[QT];
+        int nqv[QT], regq[QT];
+        int64_t tq[QT];
+        unsigned tabq[QT];
+        bf16x8_t qf[QT];
+        float m[QT];
+        f32x4_t lacc[QT], oacc[QT][2];
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const int qt = item * QT + q;
+            const bool tok = qt < ntile;                         // wave-uniform: an odd tile count leaves the last slot a duplicate
+            const int nq = (tok ? qt : ntile - 1) * 16 + fc;
+            qok[q] = tok && nq < g.N;
+            nqv[q] = nq;
+            const int nqc = nq < g.N ? nq : g.N - 1;
+            tq[q] = am_token(g, b, w, nqc);
+            const int qinf = am_info(g, nullptr, b, w, nqc);
+            tabq[q] = tab0 + (unsigned)aw_enc(C0 - (qinf & 0xffff), S3);
+            regq[q] = (qinf >> 16) & 0xff;
+            float f[8];
+            float ss = 0.f;
+            U8 x;
+            x.u = *(const uint4*)(qkv + tq[q] * rs + h * HD + fg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] = (float)x.e[e]; ss += f[e] * f[e]; }
+            const float sc = tau * LOG2E / fmaxf(sqrtf(sum4g(ss)), 1e-12f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[q][e] = (bf16)(f[e] * sc);
+            m[q] = -INFINITY;
+            lacc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            oacc[q][0] = lacc[q]; oacc[q][1] = lacc[q];
+        }
+        int kb = 0;
+        if (MASK && wmask) {
+            for (; kb < nfull64; kb += 64) aw_fwd_block<true, false, 4, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+            for (; kb < Np; kb += 32) aw_fwd_block<true, true, 2, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+        } else {
+            for (; kb < nfull64; kb += 64) aw_fwd_block<false, false, 4, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+            for (; kb < Np; kb += 32) aw_fwd_block<false, true, 2, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+        }
+#pragma unroll
+        for (int q = 0; q < QT; ++q) {
+            const float l = lacc[q][0];
+            if (qok[q]) {
+                const float inv = 1.0f / l;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    U4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(oacc[q][d][r] * inv);
+                    *(uint2*)(out + tq[q] * C + h * HD + d * 16 + 4 * fg) = o.u;
+                }
+                if (fg == 0) lse[lse0 + nqv[q]] = (m[q] + __log2f(l)) * LN2;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static int am_check(const char* fn, int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift) {
     MV_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "%s: mode %d", fn, mode);
@@ -1165,6 +1430,24 @@ static std::atomic<int> g_am_tail{-1};
 extern "C" int mvuld_set_attn_tail_split(int on) {
     g_am_tail.store(on ? 1 : 0, std::memory_order_relaxed);
     return 0;
+}
+// Forward window fast path (attn_fwd_win_k) for MODE 0, head_dim 32, window side % 4 == 0.  MVULD_ATTN_WIN / mvuld_set_attn_win:
+// 1 (default) = fast path with the deferred maximum, 2 = fast path on the general kernel's exact schedule (bit-identical to it: test),
+// 0 = the general kernel.
+static std::atomic<int> g_am_win{-1};
+extern "C" int mvuld_set_attn_win(int mode) {
+    g_am_win.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+    return 0;
+}
+static int am_win_mode() {
+    int v = g_am_win.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_ATTN_WIN");
+        v = e ? atoi(e) : 1;
+        v = v < 0 ? 0 : (v > 2 ? 2 : v);
+        g_am_win.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 static void am_plan(AttnGeom& g, int64_t groups, int ntile, int& split, unsigned& grid) {
     static const int cus = [] {
@@ -1239,7 +1522,18 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
         hipLaunchKernelGGL((attn_fwd_mfma_k<HDV, MODEV, MASKV>), grid, dim3(fwd_threads), bytes, stream, g, (const bf16*)qkv, table16, \
                            logit_scale, valid, (bf16*)out, lse, Npad, qsplit);                                  \
     } while (0)
-    if (mode == 0 && hd == 32) { if (shift > 0) AM_FWD(32, 0, true); else AM_FWD(32, 0, false); }
+    const int S3 = aw_stride_bytes(T2);
+    const size_t bytes_win = (size_t)2 * Npad * 64 + (size_t)Npad * 4 + (size_t)((Npad + 63) / 64) * 64 + (size_t)3 * S3;
+#define AM_FWD_WIN(MASKV, LZ)                                                                                   \
+    do {                                                                                                        \
+        if (am_set_lds(attn_fwd_win_k<MASKV, LZ>, bytes_win, "attn_fwd_win_k")) return 1;                       \
+        hipLaunchKernelGGL((attn_fwd_win_k<MASKV, LZ>), grid, dim3(1024), bytes_win, stream, g, (const bf16*)qkv, table16, logit_scale, \
+                           (bf16*)out, lse, Npad, qsplit, S3);                                                  \
+    } while (0)
+    const int win = am_win_mode();
+    if (mode == 0 && hd == 32 && (ws & 3) == 0 && bytes_win <= 160 * 1024 && win == 1) { if (shift > 0) AM_FWD_WIN(true, true); else AM_FWD_WIN(false, true); }
+    else if (mode == 0 && hd == 32 && (ws & 3) == 0 && bytes_win <= 160 * 1024 && win == 2) { if (shift > 0) AM_FWD_WIN(true, false); else AM_FWD_WIN(false, false); }
+    else if (mode == 0 && hd == 32) { if (shift > 0) AM_FWD(32, 0, true); else AM_FWD(32, 0, false); }
     else if (mode == 0) { if (shift > 0) AM_FWD(64, 0, true); else AM_FWD(64, 0, false); }
     else if (hd == 32) AM_FWD(32, 1, false);
     else AM_FWD(64, 1, false);

@@ -593,6 +593,36 @@ def test_swin_window_attention(gpu, dtype, impl, res, ws, shift, H):
     assert rel(dls, l_.grad) < (tol(dtype) * k if impl == "simple" else 0.3)
 
 
+@pytest.mark.parametrize("res,ws,shift,H", [(56, 28, 14, 2), (28, 28, 0, 3), (16, 8, 4, 2), (24, 12, 6, 1), (8, 4, 0, 2), (40, 20, 10, 1), (112, 28, 14, 1)])
+def test_window_fast_path_forward(gpu, res, ws, shift, H):
+    """Round 3: the forward window fast path (attention_mfma.hip attn_fwd_win_k: three shifted copies of the bias table read with aligned
+    8-byte LDS reads, one offset word read per block, two query tiles per wave) against the general kernel (mvuld_set_attn_win(0)).
+    Mode 2 keeps the general kernel's arithmetic, block sizes and accumulation order: out and lse must be equal BIT FOR BIT.  Mode 1
+    (default) defers the running maximum (it moves only when a block exceeds it by 2^6), which changes the scale at which P is rounded to
+    bf16: out agrees to bf16 rounding, lse to fp32 rounding.  Geometries: shifted (masked last row / column of windows) and unshifted,
+    N a multiple of 64 (no tail block), tails of 16 + 16 padding positions, a window smaller than one block, an odd tile count (a duplicate
+    slot in the last pair) and stage 0's 16 windows."""
+    from mvuld_amd import ops, hip
+    B, hd = 2, 32
+    C = H * hd
+    T2 = (2 * ws - 1) ** 2
+    qkv = dev(rt(T("wq", (B * res * res, 3 * C), -2, 2), torch.bfloat16), torch.bfloat16)
+    table, ls = dev(T("wt", (T2, H), 0.0, 16.0)), dev(T("wls", (H,), 1.5, 5.0))
+    g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+    got = {}
+    try:
+        for mode in (0, 1, 2):
+            hip.LIB.fn("mvuld_set_attn_win")(mode)
+            out, lse = ops.attn_fwd(g, qkv, table, ls)
+            torch.cuda.synchronize()
+            got[mode] = (out, lse)
+    finally:
+        hip.LIB.fn("mvuld_set_attn_win")(1)
+    assert torch.equal(got[2][0], got[0][0]) and torch.equal(got[2][1], got[0][1]), (rel(got[2][0], got[0][0]), rel(got[2][1], got[0][1]))
+    assert rel(got[1][0], got[0][0]) < 1e-2 and rel(got[1][1], got[0][1]) < 1e-4, (rel(got[1][0], got[0][0]), rel(got[1][1], got[0][1]))
+    assert bool(torch.isfinite(got[1][0].float()).all()) and bool(torch.isfinite(got[1][1]).all())
+
+
 @pytest.mark.parametrize("dtype,impl", [(torch.float32, "simple"), (torch.bfloat16, "simple"), (torch.bfloat16, "auto")])
 @pytest.mark.parametrize("hd,L", [(32, 100), (64, 100), (64, 512)])
 def test_padmask_attention(gpu, dtype, impl, hd, L):

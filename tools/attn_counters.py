@@ -11,13 +11,14 @@ src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof/attn_{tag.split('_
 
 
 def short(n):
-    m = re.search(r"(attn_\w+?_k)I?L?i?(\d+)ELi(\d+)(?:ELb(\d))?", n)
-    if m:
-        return f"{m.group(1)}<hd{m.group(2)},{'G' if 'dbias' in n else 'mode'}{m.group(3)}{',mask' if m.group(4) == '1' else ''}>"
-    m = re.search(r"(attn_\w+_k)<(\d+), (\d+)(?:, (true|false))?", n)
-    if m:
-        return f"{m.group(1)}<hd{m.group(2)},{'G' if 'dbias' in n else 'mode'}{m.group(3)}{',mask' if m.group(4) == 'true' else ''}>"
-    return None
+    m = re.search(r"(attn_\w+?_k)(?:I(.*?)E?Ev|<([^>]*)>)", n)
+    if not m or "reduce" in n:
+        return None
+    if m.group(3) is not None:
+        args = [a.strip() for a in m.group(3).split(",")]
+    else:           # mangled: ILi32ELi0ELb1E...
+        args = [("true" if v == "1" else "false") if t == "b" else v for t, v in re.findall(r"L([ib])(\d+)E", "L" + m.group(2).lstrip("L") + "E")]
+    return f"{m.group(1)}<{','.join(args)}>"
 
 
 def geometry(kernel, grid, wg):
