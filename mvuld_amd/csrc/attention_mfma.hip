@@ -37,11 +37,24 @@ struct AttnGeom {
 __device__ __forceinline__ unsigned am_seed(const AttnGeom& g) {
     return g.drop_off ? g.drop_seed ^ (unsigned)(g.drop_off[0] * 0x9E3779B97F4A7C15ULL >> 32) : g.drop_seed;
 }
-__device__ __forceinline__ bool am_keep(unsigned elem, unsigned seed, unsigned thr) {
-    unsigned x = elem ^ seed;
+// Round 3: ONE 32-bit hash serves the two keys of an aligned pair (2j, 2j+1) of a query row -- the counter is row * ceil(N/2) + j, the
+// even key takes bits 0..14, the odd key bits 16..30, and a key is kept when its 15-bit field >= thr15 = round(p * 2^15) (keep
+// probability exactly 1 - thr15 / 2^15, the scale is its reciprocal).  The two 32-bit multiplies of the hash were most of the text
+// encoder's attention VALU work (301 vs 108 vector instructions per 64-key forward block with / without dropout).  drop_thr carries
+// (thr15 - 1) in both halves: the packed 16-bit subtraction (thr15 - 1) - field is negative exactly where the key is kept, and its
+// sign, smeared over the half by a packed arithmetic shift, is the keep mask of the packed bf16 probability pair.
+__device__ __forceinline__ unsigned am_hash(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x >= thr;
+    return x;
 }
+typedef short __attribute__((ext_vector_type(2))) s16x2_t;
+__device__ __forceinline__ unsigned am_keep2(unsigned pairctr, unsigned seed, unsigned thr2m1) {          // 0xFFFF in the halves that are kept
+    const unsigned f = am_hash(pairctr ^ seed) & 0x7FFF7FFFu;
+    const s16x2_t d = __builtin_bit_cast(s16x2_t, thr2m1) - __builtin_bit_cast(s16x2_t, f);
+    return __builtin_bit_cast(unsigned, d >> (s16x2_t){15, 15});
+}
+// quad_perm [1, 0, 3, 2]: the value of the lane's neighbour (lane ^ 1)
+__device__ __forceinline__ unsigned am_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
 typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
@@ -261,7 +274,7 @@ template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = f
 __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const bf16* __restrict__ Vs, const int* __restrict__ Kinfo, int kb,
                                              const bf16x8_t (&qf)[HD / 32], const char* tabq, int regq, int vq, int lane, float& m,
                                              f32x4_t& lacc, f32x4_t (&oacc)[HD / 16], const bf16x8_t& ones, unsigned ebase = 0,
-                                             unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
+                                             unsigned dseed = 0, unsigned dthr = 0) {
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT];
     int ki[NT][4];
@@ -292,12 +305,10 @@ __device__ __forceinline__ void am_fwd_block(const bf16* __restrict__ Ks, const 
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
             const f32x2_t p = am_exp2((f32x2_t){s[t][2 * hp], s[t][2 * hp + 1]} - mn2);
-            if (DROP) {
-                f32x2_t pd;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) pd[e] = am_keep(ebase + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? p[e] * dinv : 0.f;
-                puw[t >> 1][(t & 1) * 2 + hp] = am_pk(p);
-                pw[t >> 1][(t & 1) * 2 + hp] = am_pk(pd);
+            if (DROP) {           // ebase = row * ceil(N/2); the kept probabilities are scaled by 1/(1-p) once, at the end (O * dinv / l)
+                const unsigned u = am_pk(p);
+                puw[t >> 1][(t & 1) * 2 + hp] = u;
+                pw[t >> 1][(t & 1) * 2 + hp] = u & am_keep2(ebase + (unsigned)((kb >> 1) + 8 * t + 2 * fg + hp), dseed, dthr);
             } else {
                 pw[t >> 1][(t & 1) * 2 + hp] = am_pk(p);
             }
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
-    const bool drop = MODE == 1 && g.drop_thr != 0;
+    const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
@@ -402,11 +413,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
         for (int d = 0; d < HD / 16; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int kb = 0;
         if (MODE == 1 && drop) {
-            const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * NL;           // element (b, h, q, k) -> 32-bit counter
+            const unsigned eb = ((unsigned)lse0 + (unsigned)nqc) * ((NL + 1) >> 1);           // (b, h, q) row -> first key-pair counter
             for (; kb < nfull64; kb += 64)
-                am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
+                am_fwd_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr);
             for (; kb < Np; kb += 32)
-                am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr, g.drop_inv);
+                am_fwd_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Ks, Vs, Kinfo, kb, qf, tabq, regq, vq, lane, m, lacc, oacc, ones, eb, dseed, g.drop_thr);
         } else {
 #define AM_FWD_SWEEP(MK)                                                                                                                       \
             if (g4) {                                                                                                                          \
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
         }
         const float l = lacc[0];             // every row of ones . P^T is the same sum over ALL keys: no cross-lane reduce
         if (qok) {
-            const float inv = 1.0f / l;
+            const float inv = drop ? g.drop_inv / l : 1.0f / l;
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) {
                 U4 o;
@@ -480,10 +491,10 @@ __device__ __forceinline__ void am_dq_block(const bf16* __restrict__ Ks, const b
                     sv[0] = am_mask<MODE, MASK, TAIL>(sv[0], ki[t][2 * hp], regq[q], vq[q]);
                     sv[1] = am_mask<MODE, MASK, TAIL>(sv[1], ki[t][2 * hp + 1], regq[q], vq[q]);
                 }
-                if (DROP) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        dpv[e] = (am_keep(ebase[q] + kb + 16 * t + 4 * fg + 2 * hp + e, dseed, dthr) ? dpv[e] * dinv : 0.f) + negD[q][0];
+                if (DROP) {           // dS = P o (mask o dP / (1-p) - delta): the keep mask of the pair, widened to the two fp32 lanes
+                    const unsigned mk = am_keep2(ebase[q] + (unsigned)((kb >> 1) + 8 * t + 2 * fg + hp), dseed, dthr);
+                    dpv[0] = fmaf(__uint_as_float(__float_as_uint(dpv[0]) & (unsigned)((int)(mk << 16) >> 16)), dinv, negD[q][0]);
+                    dpv[1] = fmaf(__uint_as_float(__float_as_uint(dpv[1]) & (unsigned)((int)mk >> 16)), dinv, negD[q][0]);
                 }
                 dsw[q][t >> 1][(t & 1) * 2 + hp] = am_pk(am_exp2(sv - L2) * dpv);
             }
@@ -524,7 +535,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
-    const bool drop = MODE == 1 && g.drop_thr != 0;
+    const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, MODE == 0, 1.0f);
@@ -602,7 +613,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
             }
             L2q[q] = lse[lse0 + nqc[q]] * LOG2E;
             negD[q] = (f32x4_t){-Dq, -Dq, -Dq, -Dq};
-            eb[q] = ((unsigned)lse0 + (unsigned)nqc[q]) * NL;
+            eb[q] = ((unsigned)lse0 + (unsigned)nqc[q]) * ((NL + 1) >> 1);
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) dq[q][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
@@ -909,7 +920,7 @@ template <int HD, int MODE, bool MASK, bool TAIL, int NT, bool G4, bool DROP = f
 __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const bf16* __restrict__ Ds, const int* __restrict__ Qi,
                                              const float* __restrict__ Ql, const float* __restrict__ Qd, int qb, const bf16x8_t (&kf)[HD / 32],
                                              const bf16x8_t (&vf)[HD / 32], const char* tabk, int regk, int vk, int lane,
-                                             f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16], unsigned ebase = 0, unsigned NL = 0,
+                                             f32x4_t (&dk)[HD / 16], f32x4_t (&dv)[HD / 16], unsigned ebase = 0, unsigned NLh = 0,
                                              unsigned dseed = 0, unsigned dthr = 0, float dinv = 1.f) {
     const int fc = lane & 15, fg = lane >> 4;
     f32x4_t s[NT], dp[NT];
@@ -932,6 +943,16 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const f32x4_t l4 = *(const f32x4_t*)(Ql + qb + 16 * t + 4 * fg);
+        unsigned H4[4];
+        if (DROP) {
+            // The hash of (query row, key pair) serves the lanes of keys 2j and 2j + 1 (neighbours: the key is the lane): each computes the
+            // hashes of two of the tile's four query rows and they swap; ebase = (b, h) row block * ceil(N/2) + this lane's key pair.
+            const unsigned par = lane & 1;
+            const unsigned c0 = ebase + (unsigned)(qb + 16 * t + 4 * fg + 2 * par) * NLh;
+            const unsigned a = am_hash(c0 ^ dseed), b = am_hash((c0 + NLh) ^ dseed);
+            const unsigned pa = am_swap1(a), pb = am_swap1(b);
+            H4[0] = par ? pa : a; H4[1] = par ? pb : b; H4[2] = par ? a : pa; H4[3] = par ? b : pb;
+        }
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
             f32x2_t sv = {s[t][2 * hp], s[t][2 * hp + 1]};
@@ -942,15 +963,16 @@ __device__ __forceinline__ void am_dkv_block(const bf16* __restrict__ Qs, const 
             }
             const f32x2_t p = am_exp2(sv + L);                                  // L = -lse; padding queries -> NEG_BIG -> 0
             if (DROP) {
-                // element (query qb+16t+4fg+r, this lane's key): ebase already holds (b, h) and the key
+                // kept probabilities are scaled by 1/(1-p) once, on dV at the end; dS = P o (mask o dP / (1-p) - delta)
                 f32x2_t pd, ds;
+                const unsigned sh = (lane & 1) * 16, thr15m1 = dthr & 0xffffu;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int r = 2 * hp + e;
-                    const bool keep = am_keep(ebase + (unsigned)(qb + 16 * t + 4 * fg + r) * NL, dseed, dthr);
+                    const bool keep = ((H4[r] >> sh) & 0x7fffu) > thr15m1;
                     const float nd = Qd[qb + 16 * t + 4 * fg + r];
-                    pd[e] = keep ? p[e] * dinv : 0.f;
-                    ds[e] = p[e] * ((keep ? dpv[e] * dinv : 0.f) + nd);
+                    pd[e] = keep ? p[e] : 0.f;
+                    ds[e] = p[e] * fmaf(keep ? dpv[e] : 0.f, dinv, nd);
                 }
                 pw[t >> 1][(t & 1) * 2 + hp] = am_pk(pd);
                 dsw[t >> 1][(t & 1) * 2 + hp] = am_pk(ds);
@@ -992,7 +1014,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
-    const bool drop = MODE == 1 && g.drop_thr != 0;
+    const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
     int C0 = 0;
     float qmul = g.scale;
@@ -1053,11 +1075,12 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
         int qb = 0;
         if (MODE == 1 && drop) {
-            const unsigned eb = (unsigned)lse0 * NL + (unsigned)nkc;             // (b, h) row block + this lane's key; + q * NL per query
+            const unsigned NLh = (NL + 1) >> 1;
+            const unsigned eb = (unsigned)lse0 * NLh + ((unsigned)nk >> 1);      // (b, h) row block + this lane's key PAIR (unclamped: neighbours agree); + q * NLh per query
             for (; qb < nfull64; qb += 64)
-                am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
+                am_dkv_block<HD, MODE, MASK, false, 4, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NLh, dseed, g.drop_thr, g.drop_inv);
             for (; qb < Np; qb += 32)
-                am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NL, dseed, g.drop_thr, g.drop_inv);
+                am_dkv_block<HD, MODE, MASK, true, 2, false, MODE == 1>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv, eb, NLh, dseed, g.drop_thr, g.drop_inv);
         } else {
 #define AM_DKV_SWEEP(MK)                                                                                                                       \
             if (g4) {                                                                                                                          \
@@ -1072,11 +1095,12 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         }
         // dv[d][r], dk[d][r]: dim d*16 + 4*fg + r of key fc; dk was accumulated against q~ * log2(e)
         if (kok) {
+            const float dvs = drop ? g.drop_inv : 1.0f;          // dropout: dV = (mask o P)^T dO / (1-p), the scale applied once here
 #pragma unroll
             for (int d = 0; d < HD / 16; ++d) {
                 U4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)dv[d][r];
+                for (int r = 0; r < 4; ++r) o.e[r] = (bf16)(dv[d][r] * dvs);
                 *(uint2*)(dqkv + tk * rs + 2 * C + h * HD + d * 16 + 4 * fg) = o.u;
             }
         }
@@ -1490,9 +1514,11 @@ static void am_plan(AttnGeom& g, int64_t groups, int ntile, int& split, unsigned
 static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed, const uint64_t* seed_offset) {
     g.drop_thr = 0; g.drop_seed = 0; g.drop_inv = 1.f; g.drop_off = seed_offset;
     if (mode >= 1 && p > 0.f) {
-        g.drop_thr = (unsigned)((double)p * 4294967296.0);
+        const unsigned thr15 = (unsigned)((double)p * 32768.0 + 0.5);       // a key is dropped when its 15-bit hash field < thr15
+        if (thr15 == 0) return;                                             // p < 2^-16: no dropout
+        g.drop_thr = (thr15 - 1) | ((thr15 - 1) << 16);
         g.drop_seed = (unsigned)(seed ^ (seed >> 32));
-        g.drop_inv = 1.0f / (1.0f - p);
+        g.drop_inv = 32768.0f / (float)(32768u - thr15);                    // 1 / (exact keep probability)
     }
 }
 

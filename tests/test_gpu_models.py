@@ -226,16 +226,19 @@ def test_unixcoder_dropout_statistics_and_backward_replay(gpu, packed):
     o2, _ = ops.attn_fwd(mk(p, 1000), qkv, valid=valid)
     assert torch.equal(o2.float().cpu()[rows], one)
     # forward AND backward against autograd on the plain formulation with the mask rebuilt on the host from the same counter hash
-    # (element (b, h, q, k) -> ((b*H + h)*L + q)*L + k, 32-bit): any disagreement between the three passes' masks shows here
+    # (key pair (b, h, q, k >> 1) -> ((b*H + h)*L + q) * ceil(L/2) + (k >> 1), 32-bit; the even key takes bits 0..14 of the hash, the odd key
+    # bits 16..30; kept when the 15-bit field >= round(p * 2^15)): any disagreement between the three passes' masks shows here
+    thr15 = int(p * 32768.0 + 0.5)
     def keep_mask(b, h, n, seed):
         q = np.arange(n, dtype=np.uint64)[:, None]
         k = np.arange(n, dtype=np.uint64)[None, :]
-        e = (((np.uint64(b * H + h) * np.uint64(L) + q) * np.uint64(L) + k) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        x = e ^ np.uint32((seed ^ (seed >> 32)) & 0xFFFFFFFF)
+        c = (((np.uint64(b * H + h) * np.uint64(L) + q) * np.uint64((L + 1) // 2) + (k >> np.uint64(1))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x = c ^ np.uint32((seed ^ (seed >> 32)) & 0xFFFFFFFF)
         x ^= x >> np.uint32(16); x = (x.astype(np.uint64) * np.uint64(0x7feb352d) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         x ^= x >> np.uint32(15); x = (x.astype(np.uint64) * np.uint64(0x846ca68b) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         x ^= x >> np.uint32(16)
-        return torch.from_numpy(x >= np.uint32(int(p * 4294967296.0)))
+        field = (x >> (np.uint32(16) * (k & np.uint64(1)).astype(np.uint32))) & np.uint32(0x7FFF)
+        return torch.from_numpy(field >= np.uint32(thr15))
     seed = 77
     w = torch.randn(T, H * hd, generator=g).to(torch.bfloat16)
     w[~rows] = 0          # pad query rows never reach the loss in the model (masked mean): no upstream gradient there
@@ -251,7 +254,7 @@ def test_unixcoder_dropout_statistics_and_backward_replay(gpu, packed):
         for h in range(H):
             qh, kh, vh = blk[:, 0, h], blk[:, 1, h], blk[:, 2, h]
             P = torch.softmax(qh @ kh.t() * hd ** -0.5, dim=-1)
-            heads.append((P * keep_mask(b, h, n, seed) / (1 - p)) @ vh)
+            heads.append((P * keep_mask(b, h, n, seed) * (32768.0 / (32768 - thr15))) @ vh)
         ref_rows.append((r0, n, torch.cat(heads, 1)))
         row0 += n
     loss = sum((o * w[r0:r0 + n].float()).sum() for r0, n, o in ref_rows)
