@@ -121,6 +121,17 @@ int mvuld_gemm_tn_wgrad(const void* dY, int64_t ldy, const void* X, int64_t ldx,
                         float* dbias, int splitk, void* ws, int64_t ws_bytes, mvuld_stream_t stream);
 /* 0: never route mvuld_gemm_tn_wgrad to the 256 x 256-tile kernel (A/B timing, tests); 1 (default): as described above. */
 int mvuld_set_gemm_tn256(int on);
+/* The weight gradients of ONE transformer block (up to 8 products) in one launch of the 256 x 256-tile kernel plus one reduction
+ * launch: together the products have enough tiles to fill the chip with ~5-way instead of 16-21-way contraction splits, a third of
+ * the fp32 partial-slab traffic.  desc: njobs x 10 int64 {dY, ldy, X, ldx, dW, ldw, M, N, K, dbias (0 = none)}, read on the host
+ * during the call (the table travels as a kernel argument).  Every product must satisfy mvuld_gemm_tn_wgrad_group_ok (M >= 256,
+ * N, K, ldy, ldx multiples of 8, N x K at least 80 % of its 256 x 256 tiles, operands < 2 GiB); ws: caller-owned, 16-byte aligned,
+ * >= mvuld_gemm_tn_wgrad_group_workspace_bytes(desc, njobs) (-1 = not eligible), private to one stream, no initialisation needed.
+ * Same arithmetic as mvuld_gemm_tn_wgrad on the same kernel (partials summed in split order, then one fp32 atomic add per element).
+ * The autograd of the nn.Linear weights of a SwinTransformerBlock (swin_transformer_v2.py:270-306) / RobertaLayer. */
+int mvuld_gemm_tn_wgrad_group_ok(int M, int N, int K, int64_t ldy, int64_t ldx);
+int64_t mvuld_gemm_tn_wgrad_group_workspace_bytes(const int64_t* desc, int njobs);
+int mvuld_gemm_tn_wgrad_group(const int64_t* desc, int njobs, void* ws, int64_t ws_bytes, mvuld_stream_t stream);
 
 /* dst[b][c][r] = src[b][r][c]  (activation / weight transposes feeding the NT GEMM in backward) */
 int mvuld_transpose(const void* src, void* dst, int R, int C, int batch, int dtype, mvuld_stream_t stream);

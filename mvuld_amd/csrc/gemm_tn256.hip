@@ -37,11 +37,12 @@ __device__ __forceinline__ int t_off(int r, int c) { return r * 512 + ((((c >> 3
 // step into a read epoch and a matrix epoch and runs row 1 one epoch behind row 0.  Every wave still issues one slab of DMA per step
 // right after the barrier that opens its read epoch; slab c has been awaited by every wave before the barrier that opens row 0's read
 // epoch of c (row 1 waits for it at the end of its read epoch of c - 1, which closes with that barrier).  Same contraction order.
+// `bid` = index of the workgroup within its product (tile-major, splits of a tile adjacent); `force_slab`: write the partial slab even when
+// the contraction is not split (grouped launches: the shared reduction kernel adds every product's tiles into dW)
 template <bool PP>
-__global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ dY, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
-                                                       int M, int N, int K, int tiles_k, int nsplit, int per, float* __restrict__ slabs,
-                                                       float* __restrict__ dW, int64_t ldw, float* __restrict__ dbias) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tn256_body(char* smem, int bid, const bf16* __restrict__ dY, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
+                                           int M, int N, int K, int tiles_k, int nsplit, int per, float* __restrict__ slabs,
+                                           float* __restrict__ dW, int64_t ldw, float* __restrict__ dbias, bool force_slab) {
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* glb_vp;
     typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     // split-major order: the splits of one tile sit next to each other, workgroups b, b+8, ... share an XCD
-    const int tl = blockIdx.x / nsplit, ks = blockIdx.x % nsplit;
+    const int tl = bid / nsplit, ks = bid % nsplit;
     const int tn = tl / tiles_k, tk = tl % tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
     const int mslabs = (M + 31) / 32;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
             }
     }
     // acc[i][j][r] = dW[n0 + wr*128 + i*16 + 4*fg + r][k0 + wc*64 + j*16 + fr]
-    if (nsplit > 1) {
+    if (nsplit > 1 || force_slab) {
         float* mine = slabs + ((size_t)tl * nsplit + ks) * T_SLAB_FLOATS;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -218,6 +219,38 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ 
     }
 }
 
+template <bool PP>
+__global__ __launch_bounds__(512, 1) void gemm_tn256_k(const bf16* __restrict__ dY, int64_t ldy, const bf16* __restrict__ X, int64_t ldx,
+                                                       int M, int N, int K, int tiles_k, int nsplit, int per, float* __restrict__ slabs,
+                                                       float* __restrict__ dW, int64_t ldw, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn256_body<PP>(smem, blockIdx.x, dY, ldy, X, ldx, M, N, K, tiles_k, nsplit, per, slabs, dW, ldw, dbias, false);
+}
+
+// ---- grouped launch (round 3): the weight gradients of ONE transformer block in one launch.  A single product has 4-16 tiles for 256 CUs,
+// so its contraction was split 16-21 ways and every split wrote (and the reduction read back) a 256 KiB fp32 partial: 53 GB per step
+// against 18.5 GB of operands and gradients (profiles/r02_hbm_traffic.csv).  A block's four products together have ~48 tiles: one launch
+// over the job table splits each ~5 ways for the same one-round fill of the chip -- a third of the partial slabs, and one reduction
+// launch per block instead of one per product.  The table travels as a kernel argument (no device copy to keep alive).
+#define TN_MAX_JOBS 8
+struct TnJob {
+    const bf16* dY; const bf16* X; float* dW; float* dbias;
+    int64_t ldy, ldx, ldw;
+    int M, N, K, tiles_k, nsplit, per, wg0, slab0;       // wg0: first workgroup of the product; slab0: its first slab in the workspace
+};
+struct TnJobs { int n, wg_total, tiles_total, pad; int tile0[TN_MAX_JOBS + 1]; TnJob j[TN_MAX_JOBS]; };
+
+template <bool PP>
+__global__ __launch_bounds__(512, 1) void gemm_tn256_group_k(const TnJobs jobs, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAX_JOBS; ++i) ji += (i < jobs.n && (int)blockIdx.x >= jobs.j[i].wg0) ? 1 : 0;      // products sit in wg0 order
+    const TnJob& J = jobs.j[ji];
+    tn256_body<PP>(smem, blockIdx.x - J.wg0, J.dY, J.ldy, J.X, J.ldx, J.M, J.N, J.K, J.tiles_k, J.nsplit, J.per,
+                   slabs + (size_t)J.slab0 * T_SLAB_FLOATS, J.dW, J.ldw, J.dbias, true);
+}
+
 // dW += sum over splits of the partial tiles (register-order slabs): one thread per (tile, wave, fragment, lane) float4
 __global__ __launch_bounds__(256) void gemm_tn256_reduce_k(const float* __restrict__ slabs, int nsplit, int tiles_k, int N, int K,
                                                            float* __restrict__ dW, int64_t ldw) {
@@ -234,6 +267,29 @@ __global__ __launch_bounds__(256) void gemm_tn256_reduce_k(const float* __restri
     for (int r = 0; r < 4; ++r) {
         const int n = n0 + wr * 128 + i * 16 + 4 * fg + r;
         if (n < N && kk < K) atomicAdd(dW + (int64_t)n * ldw + kk, s[r]);
+    }
+}
+
+// the same for a job table: blockIdx = (tile over all products) * 64 + part
+__global__ __launch_bounds__(256) void gemm_tn256_group_reduce_k(const TnJobs jobs, const float* __restrict__ slabs) {
+    const int gt = blockIdx.x >> 6;
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAX_JOBS; ++i) ji += (i < jobs.n && gt >= jobs.tile0[i]) ? 1 : 0;
+    const TnJob& J = jobs.j[ji];
+    const int tl = gt - jobs.tile0[ji];
+    const int pos = ((blockIdx.x & 63) << 8) + threadIdx.x;
+    const int lane = pos & 63, frag = (pos >> 6) & 31, wave = pos >> 11;
+    const int i = frag >> 2, j = frag & 3, wr = wave >> 2, wc = wave & 3, fr = lane & 15, fg = lane >> 4;
+    const float* p = slabs + ((size_t)J.slab0 + (size_t)tl * J.nsplit) * T_SLAB_FLOATS + (size_t)pos * 4;
+    f32x4_t s = *(const f32x4_t*)p;
+    for (int k = 1; k < J.nsplit; ++k) s += *(const f32x4_t*)(p + (size_t)k * T_SLAB_FLOATS);
+    const int n0 = (tl / J.tiles_k) * 256, k0 = (tl % J.tiles_k) * 256;
+    const int kk = k0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 128 + i * 16 + 4 * fg + r;
+        if (n < J.N && kk < J.K) atomicAdd(J.dW + (int64_t)n * J.ldw + kk, s[r]);
     }
 }
 
@@ -337,5 +393,76 @@ int mvuld_gemm_tn256_try(const void* dY, int64_t ldy, const void* X, int64_t ldx
                            K, tiles_k, nsplit, per, (float*)ws, dW, ldw, dbias);
     if (nsplit > 1)
         hipLaunchKernelGGL(gemm_tn256_reduce_k, dim3(tiles * 64), dim3(256), 0, stream, (const float*)ws, nsplit, tiles_k, N, K, dW, ldw);
+    return 0;
+}
+
+// ---- grouped launch, host side.  desc: njobs x 10 int64 {dY, ldy, X, ldx, dW, ldw, M, N, K, dbias}.
+static bool tn256_group_shape_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx) {
+    static const int max_pad4 = [] { const char* e = getenv("MVULD_TN256_MAX_PAD4"); const int v = e ? atoi(e) : 5; return v >= 4 ? v : 5; }();
+    if (M < 256 || N % 8 || K % 8 || ldy % 8 || ldx % 8) return false;
+    if (cdiv(N, 256) * 256 * cdiv(K, 256) * 256 * 4 > N * K * max_pad4) return false;
+    return M * ldy * 2 < (int64_t)0x7fffffff && M * ldx * 2 < (int64_t)0x7fffffff;
+}
+extern "C" int mvuld_gemm_tn_wgrad_group_ok(int M, int N, int K, int64_t ldy, int64_t ldx) { return tn256_group_shape_ok(M, N, K, ldy, ldx) ? 1 : 0; }
+
+static int tn256_group_plan(const int64_t* desc, int njobs, TnJobs& T) {
+    if (njobs < 1 || njobs > TN_MAX_JOBS) return -1;
+    int64_t steps = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const int64_t* d = desc + 10 * i;
+        if (!tn256_group_shape_ok(d[6], d[7], d[8], d[1], d[3])) return -1;
+        steps += cdiv(d[7], 256) * cdiv(d[8], 256) * ((d[6] + 31) / 32);
+    }
+    const int cus = tn256_num_cus();
+    int64_t target = cdiv(steps, cus);                   // 32-token slabs per workgroup for one full round of the chip
+    if (target < 8) target = 8;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        int wg = 0, slab = 0, tile = 0;
+        for (int i = 0; i < njobs; ++i) {
+            const int64_t* d = desc + 10 * i;
+            TnJob& J = T.j[i];
+            J.dY = (const bf16*)d[0]; J.ldy = d[1]; J.X = (const bf16*)d[2]; J.ldx = d[3]; J.dW = (float*)d[4]; J.ldw = d[5];
+            J.M = (int)d[6]; J.N = (int)d[7]; J.K = (int)d[8]; J.dbias = (float*)d[9];
+            J.tiles_k = (int)cdiv(J.K, 256);
+            const int tiles = (int)cdiv(J.N, 256) * J.tiles_k, mslabs = (J.M + 31) / 32;
+            int ns = (int)((mslabs + target / 2) / target);
+            if (ns < 1) ns = 1;
+            J.per = (int)cdiv(mslabs, ns);
+            J.nsplit = (int)cdiv(mslabs, J.per);
+            J.wg0 = wg; J.slab0 = slab;
+            T.tile0[i] = tile;
+            wg += tiles * J.nsplit; slab += tiles * J.nsplit; tile += tiles;
+        }
+        T.tile0[njobs] = tile;
+        T.n = njobs; T.wg_total = wg; T.tiles_total = tile; T.pad = 0;
+        if (wg <= cus || target >= steps) return 0;
+        target += (target + 15) / 16;                    // a few workgroups over one round: longer splits
+    }
+    return 0;
+}
+extern "C" int64_t mvuld_gemm_tn_wgrad_group_workspace_bytes(const int64_t* desc, int njobs) {
+    TnJobs T;
+    if (tn256_group_plan(desc, njobs, T)) return -1;
+    return (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
+}
+extern "C" int mvuld_gemm_tn_wgrad_group(const int64_t* desc, int njobs, void* ws, int64_t ws_bytes, hipStream_t stream) {
+    TnJobs T;
+    MV_CHECK_ARG(desc && njobs >= 1 && njobs <= TN_MAX_JOBS, "gemm_tn_wgrad_group: 1..%d products per launch", TN_MAX_JOBS);
+    MV_CHECK_ARG(tn256_group_plan(desc, njobs, T) == 0, "gemm_tn_wgrad_group: a product is not eligible (mvuld_gemm_tn_wgrad_group_ok)");
+    for (int i = 0; i < njobs; ++i)
+        MV_CHECK_ARG(T.j[i].dY && T.j[i].X && T.j[i].dW && ((((uintptr_t)T.j[i].dY) | ((uintptr_t)T.j[i].X)) & 15) == 0, "gemm_tn_wgrad_group: product %d: null / misaligned operand", i);
+    const int64_t need = (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
+    MV_CHECK_ARG(ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0, "gemm_tn_wgrad_group: workspace too small (%lld < %lld bytes) or misaligned",
+                 (long long)ws_bytes, (long long)need);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_group_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_group_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    if (tn256_pingpong()) hipLaunchKernelGGL(gemm_tn256_group_k<true>, dim3(T.wg_total), dim3(512), T_LDS_BYTES, stream, T, (float*)ws);
+    else hipLaunchKernelGGL(gemm_tn256_group_k<false>, dim3(T.wg_total), dim3(512), T_LDS_BYTES, stream, T, (float*)ws);
+    hipLaunchKernelGGL(gemm_tn256_group_reduce_k, dim3(T.tiles_total * 64), dim3(256), 0, stream, T, (const float*)ws);
+    MV_LAUNCH_CHECK("gemm_tn_wgrad_group");
     return 0;
 }

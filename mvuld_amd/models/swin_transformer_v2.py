@@ -116,6 +116,12 @@ class _SwinBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale = ctx.saved_tensors
+        with ops.wgrad_group():               # the block's four weight gradients: one grouped launch when the group closes
+            return _SwinBlockFn._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
+        x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale = ctx.saved_tensors
         blk, geom = ctx.blk, ctx.geom
         a = blk.attn
         ad = x.dtype

@@ -260,6 +260,11 @@ class _LayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with ops.wgrad_group():               # the layer's four weight gradients: one grouped launch when the group closes
+            return _LayerFn._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2 = ctx.saved_tensors
         layer, geom = ctx.layer, ctx.geom
         ad = x.dtype

@@ -436,6 +436,69 @@ def _tn_workspace(device, nbytes):
     return ws
 
 
+# Grouped weight gradients (round 3): inside `with wgrad_group():` -- one transformer block's backward -- the eligible bf16 weight
+# gradients are collected and issued as ONE launch of the 256 x 256-tile kernel over a job table (+ one reduction launch) when the
+# group closes: together a block's products fill the chip with ~5-way instead of 16-21-way contraction splits, i.e. a third of the
+# fp32 partial-slab traffic (csrc/gemm_tn256.hip).  Nothing in backward reads a weight gradient, so deferring them to the end of the
+# block changes no dependency; operands stay referenced by the pending list until the launch.
+USE_WGRAD_GROUPS = [os.environ.get("MVULD_WGRAD_GROUP", "1") != "0"]
+_WGRAD_PENDING = [None]
+
+
+class wgrad_group:
+    def __enter__(self):
+        self.outer = _WGRAD_PENDING[0]
+        if USE_WGRAD_GROUPS[0] and self.outer is None:
+            _WGRAD_PENDING[0] = []
+        return self
+
+    def __exit__(self, *exc):
+        if self.outer is None and _WGRAD_PENDING[0] is not None:
+            try:
+                if exc[0] is None:
+                    wgrad_group_flush()
+            finally:
+                _WGRAD_PENDING[0] = None
+        return False
+
+
+def wgrad_group_flush():
+    """Issue the pending weight gradients (on the weight-gradient stream when one is active); returns the stream they went to."""
+    jobs = _WGRAD_PENDING[0]
+    dev = jobs[0][0].device if jobs else None
+    if not jobs:
+        return None
+    _WGRAD_PENDING[0] = []
+    import ctypes
+    wg = wgrad_stream_for_current()
+    cur = torch.cuda.current_stream(dev)
+    if wg is not None:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        wg.wait_event(ev)
+        for dy, x, gw, bias_dst, M, N, K in jobs:
+            dy.record_stream(wg)
+            x.record_stream(wg)
+            if bias_dst is not None:
+                bias_dst.record_stream(wg)
+    with torch.cuda.stream(wg if wg is not None else cur):
+        for i in range(0, len(jobs), 8):
+            chunk = jobs[i:i + 8]
+            desc = (ctypes.c_int64 * (10 * len(chunk)))()
+            flops = 0.0
+            for k, (dy, x, gw, bias_dst, M, N, K) in enumerate(chunk):
+                desc[10 * k:10 * k + 10] = [dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(), K, M, N, K,
+                                            bias_dst.data_ptr() if bias_dst is not None else 0]
+                flops += 2.0 * M * N * K
+            need = hip.LIB.fn("mvuld_gemm_tn_wgrad_group_workspace_bytes")(ctypes.addressof(desc), len(chunk))
+            if need < 0:
+                raise RuntimeError("mvuld_gemm_tn_wgrad_group: ineligible product in a group")
+            ws = _tn_workspace(dev, need)
+            hip.TIMING.annotate("gemm_tn_wgrad", flops)
+            call("gemm_tn_wgrad_group", ctypes.addressof(desc), len(chunk), ptr(ws), ws.numel())
+    return wg if wg is not None else cur
+
+
 def _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk):
     ws = _tn_workspace(dy.device, hip.LIB.fn("mvuld_gemm_tn_wgrad_workspace_bytes")(M, N, K, splitk)) if USE_TN_SLABS[0] else None
     call("gemm_tn_wgrad", ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(gw), K, M, N, K, ptr(bias_dst), splitk,
@@ -491,10 +554,16 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
         f1, f2 = tiles * sk1 / 512.0, tiles * sk2 / 1024.0
         splitk = sk1 if (f1 >= 0.9 or f2 <= f1 + 0.05) else sk2
         splitk = max(1, min(math.ceil(M / 64 / 4), splitk))
-        hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
         bias_dst = bias_out if bias_out is not None else (grad_of(b_param) if b_param is not None else None)
         gw = grad_of(w_param)
         wg = wgrad_stream_for_current()
+        if (_WGRAD_PENDING[0] is not None and dy.stride(1) == 1 and x.stride(1) == 1
+                and hip.LIB.fn("mvuld_gemm_tn_wgrad_group_ok")(M, N, K, dy.stride(0), x.stride(0))):
+            _WGRAD_PENDING[0].append((dy, x, gw, bias_dst, M, N, K))
+            if bias_out is not None:          # the caller reads bias_out next: the group closes here
+                return wgrad_group_flush()
+            return wg if wg is not None else torch.cuda.current_stream(dy.device)
+        hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
         if wg is None:
             _tn_wgrad_call(dy, x, gw, bias_dst, M, N, K, splitk)
         else:

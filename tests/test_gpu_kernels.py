@@ -920,6 +920,47 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(1)
 
 
+@pytest.mark.parametrize("M,shapes", [(6272, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),          # a Swin stage-2 block (fc2, fc1, proj, qkv)
+                                      (9917, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),          # a RoBERTa layer on a ragged packed token count
+                                      (3136, [(1024, 4096), (4096, 1024), (384, 128), (1024, 1024), (3072, 1024)])])   # stage 3 + one ineligible product
+def test_gemm_tn_wgrad_grouped(gpu, M, shapes):
+    """Round 3: the weight gradients of one transformer block in ONE launch of the 256 x 256-tile kernel over a job table (+ one reduction
+    launch), ops.wgrad_group / mvuld_gemm_tn_wgrad_group.  Every product must equal dY^T X (+ what the gradient buffer held) and its bias
+    gradient colsum(dY); products the grouped kernel does not take (N x K far from filling 256 x 256 tiles) fall through to the
+    single-product path inside the same group; a second group accumulates on top of the first; the split plan of a group differs from a
+    lone product's, so equality with the ungrouped path is to fp32 summation order, not bit for bit."""
+    from mvuld_amd import ops, hip
+    prods = []
+    for i, (N, K) in enumerate(shapes):
+        dy, x = rt(T(f"gdy{i}", (M, N)), torch.bfloat16), rt(T(f"gx{i}", (M, K)), torch.bfloat16)
+        w, b = torch.nn.Parameter(torch.zeros(N, K, device=gpu)), torch.nn.Parameter(torch.zeros(N, device=gpu))
+        w.grad, b.grad = torch.ones(N, K, device=gpu), torch.ones(N, device=gpu)
+        prods.append((dy, x, dev(dy, torch.bfloat16), dev(x, torch.bfloat16), w, b))
+    assert ops.USE_WGRAD_GROUPS[0]
+    taken = sum(int(hip.LIB.fn("mvuld_gemm_tn_wgrad_group_ok")(M, N, K, N, K)) for N, K in shapes)
+    assert taken >= 4
+    for rep in (1, 2):
+        with ops.wgrad_group():
+            for dy, x, gdy, gx, w, b in prods:
+                ops.linear_wgrad(gdy, gx, w, b)
+            assert len(ops._WGRAD_PENDING[0]) == taken          # deferred, not launched yet
+        assert ops._WGRAD_PENDING[0] is None
+        for dy, x, gdy, gx, w, b in prods:
+            assert rel(w.grad, rep * (dy.t() @ x) + 1.0) < 2e-3
+            assert rel(b.grad, rep * dy.sum(0) + 1.0) < 2e-3
+    # against the ungrouped path on the same operands
+    ops.USE_WGRAD_GROUPS[0] = False
+    try:
+        for dy, x, gdy, gx, w, b in prods:
+            g2 = w.grad.clone()
+            w.grad.zero_(); b.grad.zero_()
+            with ops.wgrad_group():
+                ops.linear_wgrad(gdy, gx, w, b)
+            assert rel(2.0 * w.grad + 1.0, g2) < 1e-5
+    finally:
+        ops.USE_WGRAD_GROUPS[0] = True
+
+
 @pytest.mark.parametrize("B,h,w,S", [(2, 600, 800, 448), (1, 300, 200, 448), (3, 448, 448, 448), (1, 1000, 448, 448), (2, 97, 1301, 448),
                                      (1, 448, 900, 224)])
 def test_image_ingest_matches_pillow_restatement(gpu, B, h, w, S):
