@@ -94,7 +94,12 @@ typedef long __attribute__((ext_vector_type(2))) i64x2_t;
 // last step occupied has been read by every wave -- and skips the issue at the next tile's first barrier.  The stores are then younger
 // than every load in flight: the first NS steps of a tile may leave them pending (NS - 1 before), a K = 128 tile never waits for its
 // predecessor's stores at all.  The DMA stream then runs up to two tiles ahead, hence three bias slices instead of two.
-template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false, bool EI = false>
+// NF = "N full" (host: N % 64 == 0; used for the aux-reading epilogues): every wave's 64 columns are either all inside the matrix or all
+// outside, so a wave outside skips its epilogue and a wave inside stores UNCONDITIONALLY -- rows past M go to row M - 1, whose values they
+// duplicate exactly (the DMA clamps the operand rows the same way).  hipcc cannot count stores behind the `row < M && col < N` branch and
+// then waits for (nearly) all of a tile's stores in front of the last rows' aux values (section 9b item 15 of DESIGN.md); without the
+// branch the waits are counted.
+template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false, bool EI = false, bool NF = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
@@ -395,6 +400,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         int m0, n0;
         tile_of(ord, m0, n0);
         const int nw = n0 + wc * 64, mw = m0 + wr * WM;
+        if constexpr (NF) {
+            if (nw >= g.N) { pend = 0; continue; }       // wave-uniform: nothing of this wave's 64 columns exists
+        }
         float alpha = g.alpha;
         if (FP8) alpha *= (g.scale_a ? g.scale_a[0] : 1.0f) * (g.scale_b ? g.scale_b[0] : 1.0f);      // per-tensor dequantisation
         const float qinv = QE ? 1.0f / g.q_scale[0] : 0.f;
@@ -471,7 +479,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 const int j0 = 2 * jp;
                 // after the swaps this lane owns columns  nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8 .. + 7  of `row`
                 const int col = nw + (j0 + (fg & 1)) * 16 + (fg >> 1) * 8;
-                const bool ok = (P256_X & 1) ? false : (row < g.M && col < g.N);
+                const bool ok = (P256_X & 1) ? false : (NF ? true : (row < g.M && col < g.N));
+                const int srow = NF ? min(row, g.M - 1) : row;      // NF: rows past M duplicate row M - 1 (identical values)
                 float x[2][4];
                 if (AUX_IN && !TWO_PASS) {
                     const uint4 zz = z[i][jp];
@@ -494,10 +503,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                         else if (EPI == EPI_ADD_AUX) t += x[h][r];
                         v[h][r] = t;
                     }
-                if (C) {
+                if (!FP8 || C) {                         // (only the fp8 form may run without a bf16 output: no branch in the bf16 kernels)
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][0], v[0][1]), pk_bf16(v[1][0], v[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(v[0][2], v[0][3]), pk_bf16(v[1][2], v[1][3]), false, false);
-                    if (ok) p_st16(C + (int64_t)row * g.ldc + col, s0[0], s1[0], s0[1], s1[1]);
+                    if (ok) p_st16(C + (int64_t)srow * g.ldc + col, s0[0], s1[0], s0[1], s1[1]);
                     if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
                 if constexpr (FP8 && EPI == EPI_GELU) {
@@ -522,12 +531,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                 if (EPI == EPI_GELU && aux) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][2], pre[0][3]), pk_bf16(pre[1][2], pre[1][3]), false, false);
-                    if (ok) p_st16(aux + (int64_t)row * g.ldaux + col, s0[0], s1[0], s0[1], s1[1]);
+                    if (ok) p_st16(aux + (int64_t)srow * g.ldaux + col, s0[0], s1[0], s0[1], s1[1]);
                     if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
             }
         }
-        const bool interior = (mw + WM <= g.M) && (nw + 64 <= g.N);      // wave-uniform: every store above was issued
+        const bool interior = NF || ((mw + WM <= g.M) && (nw + 64 <= g.N));      // wave-uniform: every store above was issued
         pend = interior ? ST1 * ((C ? 1 : 0) + ((EPI == EPI_GELU && aux) ? 1 : 0) + (QE ? 1 : 0)) : 0;
     }
     if constexpr (FP8 && EPI == EPI_GELU) {
@@ -638,6 +647,21 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
             }
         }
         constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
+        if constexpr (EPI == EPI_MUL_DGELU || EPI == EPI_ADD_AUX) {
+            // unconditional-store epilogue (template parameter NF) wherever every wave's 64 columns are all inside or all outside the
+            // matrix and the output does not alias the aux operand: bit-identical, -2..8 % on these products
+            if (g.N % 64 == 0 && g.aux != g.C) {
+                static const bool attrn = [] {
+                    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, false, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
+                    return true;
+                }();
+                (void)attrn;
+                hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, false, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m,
+                                   tiles_n);
+                return;
+            }
+        }
         static const bool attr6 = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
             return true;

@@ -135,7 +135,8 @@ EARLY_DEFAULT = int(os.environ.get("MVULD_P256_EARLY", "0"))  # ... and P256_EAR
                                          (6401, 2056, 544, 224), (6401, 2056, 544, 256), (20000, 1288, 160, 0), (20000, 1288, 160, 224),
                                          (70000, 512, 128, 0), (70000, 512, 128, 160), (769, 520, 1024, 0),
                                          (6401, 2056, 576, 128), (6401, 2056, 576, 160), (6401, 2056, 576, 192), (6401, 2056, 576, 224),
-                                         (6401, 2056, 576, 256), (20000, 1288, 192, 0), (25088, 512, 2048, 0), (16384, 2304, 768, 0)])
+                                         (6401, 2056, 576, 256), (20000, 1288, 192, 0), (25088, 512, 2048, 0), (16384, 2304, 768, 0),
+                                         (80001, 128, 512, 256), (80001, 128, 512, 0), (40000, 384, 128, 256), (33000, 192, 256, 224)])
 def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     """The persistent 256 x 256-tile kernel (csrc/gemm_p256.hip) forced on ragged shapes: M and N tails inside the last
     tiles, fewer tiles than CUs / several tiles per workgroup (the LDS-DMA ring and the bias slices run across tile
