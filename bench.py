@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--infer-batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=4, help="functions per step of the CPU baseline (BASELINE.md section 4: batch 4)")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="stop the CPU baseline's timed runs once this much time is spent")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="cap on the CPU baseline's torch threads (0 = every physical core)")
+    ap.add_argument("--no-fp8", action="store_true", help="train mode: skip the extra fp8 legs (BASELINE configs[4]: train step + batch-256 inference)")
     return ap.parse_args()
 
 
@@ -284,6 +286,50 @@ def main():
     if rank == 0 and world_size() == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(config, args)
 
+    # BASELINE configs[4] beside the headline (N = 1): the same step and the same batch-256 inference with the encoders' forward QKV / FFN
+    # products on e4m3 operands -- a second model (FUSED.DTYPE fp8), built after everything bf16 has been measured
+    fp8 = None
+    if rank == 0 and world_size() == 1 and args.dtype == "bf16" and not args.no_fp8 and not args.no_infer:
+        try:
+            import copy
+            a8 = copy.copy(args)
+            a8.dtype = "fp8"
+            del model, opt, sched, store, reducer
+            torch.cuda.empty_cache()
+            config8, model8, opt8, sched8, batch8 = build(a8, device, rank)
+            g8, im8, id8, lb8, ln8 = batch8
+            model8._mv_store.refresh_working_copy()
+            it8 = [0]
+
+            def step8():
+                lg = model8(g8, im8, id8, seq_lens=ln8)
+                l8, _ = cross_entropy(lg, lb8)
+                l8.backward()
+                opt8.clip_grad_norm_(config8.TRAIN.CLIP_GRAD)
+                opt8.step()
+                opt8.zero_grad()
+                sched8.step_update(it8[0])
+                it8[0] += 1
+                return l8
+            for _ in range(max(3, args.warmup)):          # the first pass calibrates the quantisation sites
+                step8()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                l8 = step8()
+            fence()
+            d8 = time.perf_counter() - t0
+            fp8 = {"train": {"value": round(args.batch * args.steps / d8, 3), "unit": "functions/s", "ms_per_step": round(d8 / args.steps * 1e3, 3),
+                             "final_loss": round(float(l8), 5)}}
+            inf8 = infer_leg(a8, config8, model8, device, 1)
+            fp8["inference"] = {k: inf8[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")}
+            fp8["inference"]["batch_per_gpu"] = args.infer_batch
+            fp8["what"] = "BASELINE configs[4] on one GPU: forward QKV / FFN GEMMs of both encoders in OCP e4m3 (fp32 accumulate), rest bf16"
+            from mvuld_amd import ops as _ops8
+            _ops8.FP8_FWD[0] = False
+        except Exception as e:                          # the headline must still print
+            fp8 = {"error": repr(e)}
+
     if rank == 0:
         fl = algorithmic_flops_per_function(config)
         out = {
@@ -300,7 +346,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_ms if graphed is not None else host_unthrottled_ms, 3),
                        "host_enqueue_eager_ms_per_step": round(host_unthrottled_ms, 2),
                        "text_tokens_nonpad_frac": round(float(lens.sum()) / ids.numel(), 4), "final_loss": round(loss_val, 5)},
-            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "varlen_text": varlen, "host_fed_inputs": host_fed,
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "fp8": fp8, "varlen_text": varlen, "host_fed_inputs": host_fed,
         }
         print(json.dumps(out))
     if world_size() > 1:
@@ -390,7 +436,7 @@ def make_roofline(fam, ms_per_step):
     else:
         ach = d["bytes"] / sec / 1e9
         r = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(ach * 1e9 / PEAK_HBM, 4)}
-    r.update({"traffic": measured_traffic(name), "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_hbm_traffic.csv)",
+    r.update({"traffic": measured_traffic(name), "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, newest profiles/rNN_hbm_traffic.csv)",
               "kernel": name, "launches_per_step": d["n"], "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["n"]), 2),
               "kernel_ms_per_step": round(d["ms"], 3), "step_ms": round(ms_per_step, 3), "top_kernels_ms": top})
     return r
@@ -399,8 +445,8 @@ def make_roofline(fam, ms_per_step):
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (separate --pmc passes,
     FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profile.py).  None when the summary has no such row."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.csv")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_hbm_traffic.csv") for r in (3, 2)) if os.path.exists(q)), None)
+    if path is None:
         return None
     import csv
     for row in csv.DictReader(open(path)):
@@ -441,6 +487,8 @@ def cpu_baseline(config, args):
     n = args.cpu_sample
     model_name, phys, avail = cpu_info()
     cores = max(1, min(phys, avail) if phys else avail)
+    if args.cpu_threads > 0:
+        cores = min(cores, args.cpu_threads)
     torch.set_num_threads(cores)
     sw = config.MODEL.SWINV2
     scfg = swin_ref.SwinCfg(img_size=config.DATA.IMG_SIZE, embed_dim=sw.EMBED_DIM, depths=list(sw.DEPTHS), num_heads=list(sw.NUM_HEADS),
@@ -473,7 +521,10 @@ def cpu_baseline(config, args):
     runs.sort()
     med = runs[len(runs) // 2]
     return {"value": round(n / med, 4), "unit": "functions/s", "cores": cores, "kind": "port",
-            "cpu_model": model_name, "physical_cores": phys, "threads_used": cores,
+            "cpu_model": model_name, "physical_cores": phys, "threads_used": cores, "warmups": 1, "runs": len(runs),
+            "protocol": f"BASELINE.md section 4 asks 2 warm-ups and the median of >= 5 runs of a batch-4 step; the default bench run bounds the CPU "
+                        f"leg to --cpu-budget-s ({args.cpu_budget_s:g} s): 1 warm-up + the runs that fit (--cpu-budget-s 600 gives the full protocol); "
+                        f"threads = min(physical cores, --cpu-threads {args.cpu_threads}): the oracle's batch-4 operators do not scale past one socket",
             "sample": f"batch {n}, fused fwd+CE+bwd+clip+AdamW step of the oracle (PyTorch fp32 CPU): 1 warm-up ({warm[0]:.1f} s), "
                       f"median of {len(runs)} timed runs = {med:.2f} s/step"}
 

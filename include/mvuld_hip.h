@@ -103,10 +103,6 @@ int mvuld_set_gemm_p256_k64(int on);
  * order: the stores then never sit in front of a load that is waited for within the tile's first steps), 0 = after them.
  * Bit-identical results; initialised from MVULD_P256_EARLY. */
 int mvuld_set_gemm_p256_early(int on);
-/* routing of mvuld_gemm_nt to the experimental deferred-epilogue 128 x 256 kernel (gemm_p128d.hip; measured slower than the 256-row
- * kernel, see its header): 0 never (default), 1 rule (N >= 1536, K <= 1024, >= 2 tiles per CU), 2 whenever the shape is legal;
- * initialised from MVULD_GEMM_P128D */
-int mvuld_set_gemm_p128d_mode(int mode);
 
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
  * layout, fp32 accumulate); dbias[N] += column sums of dY when non-null.  The token contraction is split over workgroups.
@@ -126,7 +122,8 @@ int mvuld_set_gemm_tn256(int on);
  * the fp32 partial-slab traffic.  desc: njobs x 10 int64 {dY, ldy, X, ldx, dW, ldw, M, N, K, dbias (0 = none)}, read on the host
  * during the call (the table travels as a kernel argument).  Every product must satisfy mvuld_gemm_tn_wgrad_group_ok (M >= 256,
  * N, K, ldy, ldx multiples of 8, N x K at least 80 % of its 256 x 256 tiles, operands < 2 GiB); ws: caller-owned, 16-byte aligned,
- * >= mvuld_gemm_tn_wgrad_group_workspace_bytes(desc, njobs) (-1 = not eligible), private to one stream, no initialisation needed.
+ * >= mvuld_gemm_tn_wgrad_group_workspace_bytes(desc, njobs) (-1 = not eligible), private to one stream; it may be the buffer handed to
+ * mvuld_gemm_tn_wgrad on the same stream (same layout: the first 4096 bytes, that entry point's zeroed ticket block, are left alone).
  * Same arithmetic as mvuld_gemm_tn_wgrad on the same kernel (partials summed in split order, then one fp32 atomic add per element).
  * The autograd of the nn.Linear weights of a SwinTransformerBlock (swin_transformer_v2.py:270-306) / RobertaLayer. */
 int mvuld_gemm_tn_wgrad_group_ok(int M, int N, int K, int64_t ldy, int64_t ldx);
@@ -295,6 +292,17 @@ int mvuld_l2norm_mean_bwd(const void* g, const void* dhf, const float* ssum, con
 /* CrossEntropyLoss + softmax: main_bigvul.py:298,330-333 */
 int mvuld_cross_entropy(const float* logits, const int64_t* target, float* loss, float* probs, float* dlogits, int B,
                         int K, float loss_scale, mvuld_stream_t stream);
+/* The Swin fine-tune job's criteria (main.py:136-140): SoftTargetCrossEntropy on mixed targets (target [B, K] fp32, target_i null) or
+ * LabelSmoothingCrossEntropy (target_i [B] int64 + smoothing, target null): loss += mean_b sum_k -t log softmax * loss_scale,
+ * dlogits = (probs * sum_k t - t) * loss_scale / B.  timm (third party) is absent from the reference tree: restated from its algorithm. */
+int mvuld_cross_entropy_soft(const float* logits, const float* target, const int64_t* target_i, float smoothing, float* loss,
+                             float* probs, float* dlogits, int B, int K, float loss_scale, mvuld_stream_t stream);
+/* timm.data.Mixup in "batch" mode (main.py:268-269, data/build.py:86-95), out of place on [B, C, H, W]: y[b] = lam x[b] + (1 - lam) x[B-1-b],
+ * or with cutmix != 0 the box rows [yl, yh) x columns [xl, xh) of x[B-1-b] pasted into x[b]; with target / soft_target the mixed,
+ * label-smoothed one-hot targets [B, K] (mixup_target: on = 1 - smoothing + smoothing / K, off = smoothing / K).  lam and the box are
+ * drawn on the host (numpy, as timm draws them). */
+int mvuld_mixup_batch(const void* x, void* y, const int64_t* target, float* soft_target, int B, int C, int H, int W, int K, float lam,
+                      int cutmix, int yl, int yh, int xl, int xh, float smoothing, int dtype, mvuld_stream_t stream);
 
 /* GATConv sparse part (dgl 0.8.1 u_add_v / edge_softmax / u_mul_e_sum; GraphModel.py:167-170) over CSR by destination */
 int mvuld_gat_scores_fwd(const void* ft, const float* al, const float* ar, float* el, float* er, int N, int H, int O,

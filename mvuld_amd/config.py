@@ -162,6 +162,7 @@ _DEFAULTS = {
         "DTYPE": "bf16",           # activation storage: bf16 | fp32 | fp8 (= bf16 + forward encoder GEMMs in e4m3)
         "HEAD": "Multi_DefectModel_new_GCN",   # any head class of models/{GraphModel,new_model,MotivationModel}.py (main_bigvul.py:124-129)
         "SYNTHETIC": True,         # synthetic Big-Vul-shaped data (there is no dataset on the box)
+        "DATA_ROOT": "",           # a corpus directory in the reference's file formats (data/bigvul_dataset.py: BigVulFiles) instead
         "SYNTH_TRAIN": 256, "SYNTH_VAL": 64, "SYNTH_TEST": 64,
         "SEQ_LEN": 512, "NODES_LO": 150, "NODES_HI": 250,
         # HIDDEN_DROPOUT / ATTN_DROPOUT: HF RobertaConfig defaults (unixcoder.py:107-110 builds the model from that config); active

@@ -507,6 +507,89 @@ extern "C" int mvuld_cross_entropy(const float* logits, const int64_t* target, f
     return 0;
 }
 
+// soft targets (timm SoftTargetCrossEntropy / LabelSmoothingCrossEntropy: main.py:136-140): loss += mean_b sum_k -t[b,k] log softmax(x[b])[k]
+// * loss_scale ; dlogits = (probs * sum_k t[b,k] - t[b]) * loss_scale / B.  `smoothing` > 0 with integer targets (target_i != null):
+// t = one-hot * (1 - smoothing) + smoothing / K  (LabelSmoothingCrossEntropy: nll * confidence + mean(-logprobs) * smoothing).
+__global__ void ce_soft_k(const float* __restrict__ logits, const float* __restrict__ target, const int64_t* __restrict__ target_i, float smoothing,
+                          float* __restrict__ loss, float* __restrict__ probs, float* __restrict__ dlogits, int B, int K, float loss_scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logits[b * K + k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(logits[b * K + k] - m);
+    const float lz = logf(s) + m;
+    const int ti = target_i ? (int)target_i[b] : -1;
+    float tsum = 0.f, l = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float t = target_i ? ((k == ti ? 1.0f - smoothing : 0.f) + smoothing / K) : target[b * K + k];
+        tsum += t;
+        l += t * (lz - logits[b * K + k]);
+    }
+    for (int k = 0; k < K; ++k) {
+        const float p = expf(logits[b * K + k] - m) / s;
+        const float t = target_i ? ((k == ti ? 1.0f - smoothing : 0.f) + smoothing / K) : target[b * K + k];
+        if (probs) probs[b * K + k] = p;
+        if (dlogits) dlogits[b * K + k] = (p * tsum - t) * loss_scale / B;
+    }
+    atomicAdd(loss, l * loss_scale / B);
+}
+extern "C" int mvuld_cross_entropy_soft(const float* logits, const float* target, const int64_t* target_i, float smoothing, float* loss,
+                                        float* probs, float* dlogits, int B, int K, float loss_scale, hipStream_t stream) {
+    MV_CHECK_ARG(logits && (target || target_i) && loss && B > 0 && K > 0, "cross_entropy_soft: bad args");
+    MV_CHECK_ARG(smoothing >= 0.f && smoothing < 1.f, "cross_entropy_soft: 0 <= smoothing < 1");
+    hipLaunchKernelGGL(ce_soft_k, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, stream, logits, target, target_i, smoothing, loss, probs, dlogits, B, K,
+                       loss_scale);
+    MV_LAUNCH_CHECK("cross_entropy_soft");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ Mixup / CutMix, batch mode (timm.data.Mixup, main.py:268-269)
+// y[b] = lam * x[b] + (1 - lam) * x[B-1-b]   (mixup)   or   x[b] with the box [yl, yh) x [xl, xh) taken from x[B-1-b]   (cutmix);
+// images [B, C, H, W] contiguous, 8 elements per lane where the row length allows.  The soft targets go with it:
+// t[b] = lam * smooth_onehot(target[b]) + (1 - lam) * smooth_onehot(target[B-1-b]),  on = 1 - smoothing + off, off = smoothing / K.
+template <typename T>
+__global__ __launch_bounds__(256) void mixup_k(const T* __restrict__ x, T* __restrict__ y, int B, int64_t per, int H, int W, float lam, int cutmix,
+                                               int yl, int yh, int xl, int xh) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)B * per;
+    if (i >= total) return;
+    const int b = (int)(i / per);
+    const int64_t r = i - (int64_t)b * per;
+    const int64_t j = (int64_t)(B - 1 - b) * per + r;
+    if (cutmix) {
+        const int w = (int)(r % W), h = (int)((r / W) % H);
+        y[i] = (h >= yl && h < yh && w >= xl && w < xh) ? x[j] : x[i];
+    } else {
+        y[i] = (T)(lam * (float)x[i] + (1.0f - lam) * (float)x[j]);
+    }
+}
+__global__ void mixup_target_k(const int64_t* __restrict__ target, float* __restrict__ out, int B, int K, float lam, float smoothing) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i % K;
+    const float off = smoothing / K, on = 1.0f - smoothing + off;
+    const float a = (int)target[b] == k ? on : off, c = (int)target[B - 1 - b] == k ? on : off;
+    out[i] = a * lam + c * (1.0f - lam);
+}
+extern "C" int mvuld_mixup_batch(const void* x, void* y, const int64_t* target, float* soft_target, int B, int C, int H, int W, int K, float lam,
+                                 int cutmix, int yl, int yh, int xl, int xh, float smoothing, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && y && x != y && B > 0 && C > 0 && H > 0 && W > 0, "mixup_batch: bad args (out of place)");
+    MV_CHECK_ARG(lam >= 0.f && lam <= 1.f && (!cutmix || (0 <= yl && yl <= yh && yh <= H && 0 <= xl && xl <= xh && xh <= W)), "mixup_batch: lam / box");
+    const int64_t per = (int64_t)C * H * W, total = (int64_t)B * per;
+    const unsigned grid = (unsigned)cdiv(total, 256);
+    if (dtype == MVULD_F32)
+        hipLaunchKernelGGL(mixup_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, B, per, H, W, lam, cutmix, yl, yh, xl, xh);
+    else
+        hipLaunchKernelGGL(mixup_k<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, B, per, H, W, lam, cutmix, yl, yh, xl, xh);
+    if (target && soft_target) {
+        MV_CHECK_ARG(K > 0 && smoothing >= 0.f && smoothing < 1.f, "mixup_batch: classes / smoothing");
+        hipLaunchKernelGGL(mixup_target_k, dim3((unsigned)cdiv((int64_t)B * K, 64)), dim3(64), 0, stream, target, soft_target, B, K, lam, smoothing);
+    }
+    MV_LAUNCH_CHECK("mixup_batch");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ Swin continuous position bias table
 // table16[i,h] = 16*sigmoid( W2[h,:] . relu(W1 . coords[i] + b1) )   coords [T2,2], W1 [512,2], b1 [512], W2 [H,512]
 // (swin_transformer_v2.py:159-163).  hidden [T2,512] is kept for the backward.

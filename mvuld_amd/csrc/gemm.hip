@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
 // dW[N,K] += dY[M,N]^T . X[M,K]  (fp32 atomic accumulate);  optional db[N] += column sums of dY
 // workspace of mvuld_gemm_tn_wgrad for an N x K weight: one 4-byte ticket per 128 x 128 output tile (kept at 0 between
 // launches by the kernel itself: the caller zeroes the buffer ONCE, when it allocates it) followed by splitk 64 KiB slabs per tile
-#define TN_TICKET_BYTES 4096
+#define TN_TICKET_BYTES 4096            // (gemm_tn256.hip: TN_GROUP_WS_HEAD must equal it)
 static int64_t tn128_workspace_bytes(int N, int K, int splitk) {
     const int64_t tiles = cdiv(N, 128) * cdiv(K, 128);
     if (splitk < 2 || tiles * 4 > TN_TICKET_BYTES) return 0;

@@ -50,8 +50,6 @@ template <typename TO> __device__ __forceinline__ float dgelu_t(float x) {
 
 // persistent 256 x 256 NT kernel (gemm_p256.hip); returns 0 when it took the launch, -1 when the shape is not its to take
 int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream);
-// persistent 128 x 256 kernel with the epilogue deferred under the next tile's main loop (gemm_p128d.hip): 0 = launched, -1 = not its shape
-int mvuld_gemm_nt_p128d_try(const GemmArgs& g, hipStream_t stream);
 // the same kernel on OCP e4m3 operands (v_mfma_f32_16x16x32_fp8_fp8): 0 = launched, -1 = shape not eligible (K % 64, K >= 256, N % 8)
 int mvuld_gemm_nt_p256_fp8(const GemmArgs& g, hipStream_t stream);
 

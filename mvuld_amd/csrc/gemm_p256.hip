@@ -829,7 +829,6 @@ int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream)
         if ((int64_t)tiles_n * P_BN * 2 > (int64_t)g.N * (tiles >= 1024 ? 4 : 3)) return -1;
     }
     int ni = g_p256_ni.load(std::memory_order_relaxed);
-    if (ni == 0 && mvuld_gemm_nt_p128d_try(g, stream) == 0) return 0;      // wide output, short contraction: deferred-epilogue kernel
     if (ni == 0) ni = p256_pick_ni(g.M, tiles_n, p256_num_cus());
     switch (g.epi) {
         case EPI_NONE: case EPI_BIAS: p256_launch_ni<EPI_BIAS>(g, ni, tiles_n, stream); break;

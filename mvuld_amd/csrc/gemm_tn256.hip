@@ -440,10 +440,13 @@ static int tn256_group_plan(const int64_t* desc, int njobs, TnJobs& T) {
     }
     return 0;
 }
+// The workspace has the layout of mvuld_gemm_tn_wgrad's: its first TN_GROUP_WS_HEAD bytes are the ticket block of the 128 x 128 kernel's
+// last-arriver reduction (zero between launches: the caller may hand the SAME per-stream buffer to both entry points) and are not touched.
+#define TN_GROUP_WS_HEAD 4096
 extern "C" int64_t mvuld_gemm_tn_wgrad_group_workspace_bytes(const int64_t* desc, int njobs) {
     TnJobs T;
     if (tn256_group_plan(desc, njobs, T)) return -1;
-    return (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
+    return TN_GROUP_WS_HEAD + (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
 }
 extern "C" int mvuld_gemm_tn_wgrad_group(const int64_t* desc, int njobs, void* ws, int64_t ws_bytes, hipStream_t stream) {
     TnJobs T;
@@ -451,9 +454,10 @@ extern "C" int mvuld_gemm_tn_wgrad_group(const int64_t* desc, int njobs, void* w
     MV_CHECK_ARG(tn256_group_plan(desc, njobs, T) == 0, "gemm_tn_wgrad_group: a product is not eligible (mvuld_gemm_tn_wgrad_group_ok)");
     for (int i = 0; i < njobs; ++i)
         MV_CHECK_ARG(T.j[i].dY && T.j[i].X && T.j[i].dW && ((((uintptr_t)T.j[i].dY) | ((uintptr_t)T.j[i].X)) & 15) == 0, "gemm_tn_wgrad_group: product %d: null / misaligned operand", i);
-    const int64_t need = (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
+    const int64_t need = TN_GROUP_WS_HEAD + (int64_t)T.wg_total * T_SLAB_FLOATS * 4;
     MV_CHECK_ARG(ws && ws_bytes >= need && (((uintptr_t)ws) & 15) == 0, "gemm_tn_wgrad_group: workspace too small (%lld < %lld bytes) or misaligned",
                  (long long)ws_bytes, (long long)need);
+    ws = (char*)ws + TN_GROUP_WS_HEAD;
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)gemm_tn256_group_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_tn256_group_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);

@@ -184,3 +184,45 @@ def make_joern_cpg(index: int, n_lines=40, salt=0):
         edge(per_line[ln][-1], ret, "CFG")
     edge(method, nodes[1]["id"], "SOURCE_FILE")
     return nodes, edges
+
+
+def write_corpus(root, splits, img_hw=(96, 128), seq_len=64, vocab=1000, line_len=16, n_lines=24, head_only=False, salt=0):
+    """Write a small corpus directory in the reference's FILE FORMATS (the layout data/bigvul_dataset.py:BigVulFiles documents) from
+    synthetic content: ``splits`` = {"train": [ids], "val": [...], "test": [...]}.  PNGs of ``img_hw`` (any size: the device transform
+    resizes), Joern exports from ``make_joern_cpg``, OCR boxes for most lines, function token ids, per-line token ids keyed by line
+    number; with ``head_only`` also the cached encoder features the reference's head-only step reads.  Test / demo helper: the real
+    corpus is an external download."""
+    import json
+    import os
+    import pickle
+    from PIL import Image
+    root = str(root)
+    for d in ("images", "func_before", "norm_pos_dict", "token_ids", "line_token_ids", "swinv2_method_level_try5"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    rows = []
+    for split, ids in splits.items():
+        with open(os.path.join(root, f"{split}.txt"), "w") as f:
+            for _id in ids:
+                f.write(f"images/{_id}.png {make_label(_id, salt)}\n")
+        for _id in ids:
+            Image.fromarray(make_image_u8(_id, *img_hw, salt=salt).numpy(), "RGB").save(os.path.join(root, "images", f"{_id}.png"))
+            nodes, edges = make_joern_cpg(_id, n_lines=n_lines, salt=salt)
+            with open(os.path.join(root, "func_before", f"{_id}.c.nodes.json"), "w") as f:
+                json.dump(nodes, f)
+            with open(os.path.join(root, "func_before", f"{_id}.c.edges.json"), "w") as f:
+                json.dump(edges, f)
+            lines = sorted({int(n["lineNumber"]) for n in nodes if n.get("lineNumber") not in (None, "")})
+            rng = np.random.default_rng(int(synth.name_seed(f"corpus/{_id}", salt)))
+            pos = {ln: rng.random(4).astype(np.float32).tolist() for ln in lines if rng.random() < 0.8}      # some lines the OCR missed
+            with open(os.path.join(root, "norm_pos_dict", f"{_id}.pkl"), "wb") as f:
+                pickle.dump(pos, f)
+            np.save(os.path.join(root, "token_ids", f"{_id}.npy"), make_ids(_id, seq_len, vocab, lo=seq_len // 4, salt=salt).numpy())
+            lids, _ = make_line_ids(_id, len(lines), length=line_len, vocab=vocab, lo=1, salt=salt)
+            np.savez(os.path.join(root, "line_token_ids", f"{_id}.npz"), lineno=np.asarray(lines, dtype=np.int64), ids=lids.numpy())
+            if head_only:
+                torch.save(synth.tensor(f"imgfeat/{_id}", (1024,)), os.path.join(root, "swinv2_method_level_try5", f"{_id}.pt"))
+                rows.append((_id, synth.tensor(f"txtfeat/{_id}", (768,)).tolist()))
+    if head_only:
+        import pandas as pd
+        pd.DataFrame({"ids": [r[0] for r in rows], "repr": [r[1] for r in rows]}).to_pickle(os.path.join(root, "result.pkl"))
+    return root

@@ -6,9 +6,13 @@ Same flags as main.py:55-98 (``--cfg --opts --patience --test --batch-size --dat
 same step order (:263-283: forward, CrossEntropy / accumulation, clip, AdamW, per-iteration cosine LR), validation metrics
 (P / R / F1 / PR-AUC, early stop on F1), ``--throughput`` (:438-455: 50 warm-up + 30 timed forwards) and checkpoint layout.
 
+Mixup / CutMix (``mixup_fn``: :268-269, data/build.py:86-95) run on the device in timm's "batch" mode with host-drawn parameters
+(data/mixup.py) and the criterion follows :136-140: SoftTargetCrossEntropy when AUG.MIXUP > 0, LabelSmoothingCrossEntropy when only
+MODEL.LABEL_SMOOTHING > 0, CrossEntropyLoss otherwise (one device kernel each).
+
 Differences: the model is this package's SwinTransformerV2 (one fused autograd function per block, bf16 activations instead of
-torch.cuda.amp autocast :271); data is synthetic (no dataset on the box); timm's Mixup / CutMix / RandAugment pipeline
-(data/build.py:146-168, :268-269) is data augmentation outside the hot path and is not applied -- the step sees hard labels.
+torch.cuda.amp autocast :271); data is synthetic (no dataset on the box), so the image-side augmentations of the training transform
+(RandAugment / colour jitter / random erasing, data/build.py:146-168) have nothing to act on and are not built.
 """
 import argparse
 import json
@@ -30,8 +34,9 @@ from mvuld_amd.logger import create_logger                                 # noq
 from mvuld_amd.lr_scheduler import build_scheduler                         # noqa: E402
 from mvuld_amd.metrics import AverageMeter, accuracy, average_precision, binary_prf  # noqa: E402
 from mvuld_amd.optimizer import build_optimizer                            # noqa: E402
-from mvuld_amd.utils_multi import (NativeScalerWithGradNormCount, auto_resume_helper, load_pretrained, load_state_dict_checked,  # noqa: E402
-                                   reduce_tensor, resume_bestf1_helper, save_bestf1_checkpoint, _after_load)
+from mvuld_amd.data.mixup import build_mixup                               # noqa: E402
+from mvuld_amd.utils_multi import (NativeScalerWithGradNormCount, auto_resume_helper, load_checkpoint, load_pretrained,  # noqa: E402
+                                   reduce_tensor, resume_bestf1_helper, save_bestf1_checkpoint)
 
 logger = None
 
@@ -94,8 +99,19 @@ def build_loaders(config):
     return sets, loaders
 
 
-def train_one_epoch(config, model, data_loader, optimizer, epoch, lr_scheduler, loss_scaler, device, max_steps=0):
+def build_criterion(config):
+    """main.py:136-140 -> f(outputs, targets, loss_scale) returning (loss, probs)."""
+    from mvuld_amd.models.GraphModel import cross_entropy, label_smoothing_cross_entropy, soft_target_cross_entropy
+    if config.AUG.MIXUP > 0.0:
+        return soft_target_cross_entropy                   # smoothing is handled with the mixup label transform
+    if config.MODEL.LABEL_SMOOTHING > 0.0:
+        return lambda o, t, loss_scale=1.0: label_smoothing_cross_entropy(o, t, config.MODEL.LABEL_SMOOTHING, loss_scale)
+    return cross_entropy
+
+
+def train_one_epoch(config, model, data_loader, optimizer, epoch, lr_scheduler, loss_scaler, device, max_steps=0, mixup_fn=None, criterion=None):
     from mvuld_amd.models.GraphModel import cross_entropy
+    criterion = criterion or cross_entropy
     model.train()
     optimizer.zero_grad()
     num_steps = len(data_loader)
@@ -104,8 +120,10 @@ def train_one_epoch(config, model, data_loader, optimizer, epoch, lr_scheduler, 
     end = time.time()
     for idx, (samples, targets) in enumerate(data_loader):
         samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)                              # :268-269 (soft targets [B, K] from here on)
         outputs = model(samples)
-        loss, _ = cross_entropy(outputs, targets, loss_scale=1.0 / acc)               # criterion / accumulation steps (:272-273)
+        loss, _ = criterion(outputs, targets, loss_scale=1.0 / acc)                    # criterion / accumulation steps (:272-273)
         update = (idx + 1) % acc == 0
         loss_scaler(loss, optimizer, clip_grad=config.TRAIN.CLIP_GRAD, parameters=None, update_grad=update)
         if update:
@@ -187,21 +205,39 @@ def my_main(config, args, device):
     store.grad_scale = 1.0 / world_size()
     loss_scaler = NativeScalerWithGradNormCount(grad_sync=reducer.finish)
     lr_scheduler = build_scheduler(config, optimizer, max(1, len(loader_train) // max(1, config.TRAIN.ACCUMULATION_STEPS)))
-    if config.TRAIN.AUTO_RESUME and not config.MODEL.RESUME:
+    # resume order of main.py:146-181: best-f1 file under OUTPUT (TRAIN.BEST_RESUME) replaces MODEL.RESUME, the checkpoint restores model,
+    # optimizer moments, LR schedule, scaler, START_EPOCH and max_accuracy (load_checkpoint); TRAIN.AUTO_RESUME then prefers the newest
+    # epoch checkpoint of OUTPUT.
+    max_acc = 0.0
+    if config.TRAIN.BEST_RESUME:
+        f = resume_bestf1_helper(config.OUTPUT)
+        if f:
+            if config.MODEL.RESUME:
+                logger.warning(f"best-resume changing resume file from {config.MODEL.RESUME} to {f}")
+            config.defrost(); config.MODEL.RESUME = f; config.freeze()
+            logger.info(f'best-f1 resuming from {f}')
+        else:
+            logger.info(f'no checkpoint found in {config.OUTPUT}/checkpoint-best-f1, ignoring best resume')
+    if config.MODEL.RESUME:
+        max_acc, _ = load_checkpoint(config, model, optimizer, lr_scheduler, loss_scaler, logger, path=config.MODEL.RESUME)
+    if config.TRAIN.AUTO_RESUME:
         f = auto_resume_helper(config.OUTPUT)
         if f:
+            if config.MODEL.RESUME:
+                logger.warning(f"auto-resume changing resume file from {config.MODEL.RESUME} to {f}")
             config.defrost(); config.MODEL.RESUME = f; config.freeze()
-    if config.MODEL.RESUME:
-        ck = torch.load(config.MODEL.RESUME, map_location='cpu', weights_only=False)
-        load_state_dict_checked(model, ck['model'], logger, config.MODEL.RESUME)
-        _after_load(model)
+            logger.info(f'auto resuming from {f}')
+            max_acc, _ = load_checkpoint(config, model, optimizer, lr_scheduler, loss_scaler, logger, path=f)
+        else:
+            logger.info(f'no checkpoint found in {config.OUTPUT}, ignoring auto resume')
     if config.EVAL_MODE or args.test:
         return validate(config, loader_test if args.test else loader_val, model, device)
     logger.info("Start training")
-    best_f1, stale, max_acc = 0.0, 0, 0.0
+    mixup_fn, criterion = build_mixup(config), build_criterion(config)
+    best_f1, stale = 0.0, 0
     for epoch in range(config.TRAIN.START_EPOCH, config.TRAIN.EPOCHS):
         loader_train.sampler.set_epoch(epoch)
-        train_one_epoch(config, model, loader_train, optimizer, epoch, lr_scheduler, loss_scaler, device, args.max_steps)
+        train_one_epoch(config, model, loader_train, optimizer, epoch, lr_scheduler, loss_scaler, device, args.max_steps, mixup_fn, criterion)
         acc1, loss, f1, prauc = validate(config, loader_val, model, device)
         max_acc = max(max_acc, acc1)
         if f1 > best_f1 and prauc != 0:
@@ -228,6 +264,8 @@ def main(argv=None):
     device = torch.device(f"cuda:{local}")
     seed = config.SEED + rank if args.seed == 0 else args.seed
     torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+    from mvuld_amd import ops as _ops
+    _ops.seed_rng(seed, rank)                          # dropout / DropPath mask streams: per seed AND per rank
     scale = config.DATA.BATCH_SIZE * world_size() / 512.0 * max(1, config.TRAIN.ACCUMULATION_STEPS)      # linear LR scaling (:main)
     config.defrost()
     config.TRAIN.BASE_LR *= scale; config.TRAIN.WARMUP_LR *= scale; config.TRAIN.MIN_LR *= scale

@@ -117,6 +117,12 @@ def model_step_inputs(batch, device, pad_token_id=1, image_size=None):
     kw = {}
     if b.dtype == torch.int64 and b.dim() == 2 and not b.is_cuda:
         kw["seq_lens"] = (b != pad_token_id).sum(1).to(torch.int32)
+    if "_token_ids" in g.ndata and "_UNIX_NODE_EMB" not in g.ndata and b.dtype == torch.int64:
+        # per-line token ids from the dataset (data_list.py:240-262 caches them as ndata["_token_ids"]): the node features are computed
+        # on the device by the fused model's text encoder (FusedMVulD.forward(node_ids=...)); lengths counted on the host
+        nid = g.ndata.pop("_token_ids")
+        kw["node_lens"] = (nid != pad_token_id).sum(1).to(torch.int32)
+        kw["node_ids"] = nid.to(device, non_blocking=True)
     g = g.to(device)
     g.index()                   # on the device (mvuld_graph_csr_build) unless the loader already built it on the host
     if isinstance(a, (list, tuple)):
@@ -357,6 +363,8 @@ def main(argv=None):
         torch.cuda.set_device(local)
     seed = args.seed                                   # the reference overwrites SEED+rank with args.seed (:533-541)
     torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+    from mvuld_amd import ops as _ops
+    _ops.seed_rng(seed, rank)                          # dropout / DropPath mask streams: per seed AND per rank
     ws = world_size()
     # linear LR scaling with the global batch (:545-558)
     scale = config.DATA.BATCH_SIZE * ws / 512.0

@@ -266,6 +266,41 @@ class _CrossEntropyFn(torch.autograd.Function):
         return out, None, None
 
 
+class _SoftCrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, smoothing, loss_scale):
+        hip.require_gpu(logits)
+        assert logits.dtype == torch.float32
+        B, K = logits.shape
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        probs, dlog = torch.empty_like(logits), torch.empty_like(logits)
+        logits, target = logits.contiguous(), target.contiguous()
+        soft = target.dtype == torch.float32
+        assert (soft and target.shape == logits.shape) or (not soft and target.dtype == torch.int64 and target.shape == (B,))
+        call("cross_entropy_soft", ptr(logits), ptr(target) if soft else None, None if soft else ptr(target), float(smoothing), ptr(loss), ptr(probs),
+             ptr(dlog), B, K, float(loss_scale))
+        ctx.save_for_backward(dlog)
+        ctx.mark_non_differentiable(probs)
+        return loss, probs
+
+    @staticmethod
+    def backward(ctx, dloss, _dp):
+        (dlog,) = ctx.saved_tensors
+        out = torch.empty_like(dlog)
+        call("scale_by_dev", ptr(dlog), ptr(dloss.to(torch.float32).contiguous()), ptr(out), dlog.numel())
+        return out, None, None, None
+
+
+def soft_target_cross_entropy(logits, target, loss_scale=1.0):
+    """timm SoftTargetCrossEntropy (main.py:136-138): mean_b sum_k -target[b,k] * log_softmax(logits)[b,k]; target [B, K] fp32."""
+    return _SoftCrossEntropyFn.apply(logits, target, 0.0, loss_scale)
+
+
+def label_smoothing_cross_entropy(logits, target, smoothing=0.1, loss_scale=1.0):
+    """timm LabelSmoothingCrossEntropy (main.py:139-140): (1 - smoothing) * nll + smoothing * mean_k(-log_softmax); target [B] int64."""
+    return _SoftCrossEntropyFn.apply(logits, target, smoothing, loss_scale)
+
+
 def cross_entropy(logits, target, loss_scale=1.0):
     """(mean CE * loss_scale, softmax probs): CrossEntropyLoss + F.softmax of main_bigvul.py:298,330-333."""
     return _CrossEntropyFn.apply(logits, target, loss_scale)

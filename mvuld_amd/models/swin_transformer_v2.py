@@ -426,7 +426,7 @@ class SwinTransformerV2(nn.Module):
         for i, bly in enumerate(self.layers):
             bly._init_respostnorm()
             bly.blocks[0]._backward_done_tag = f"swin.layers.{i}"      # fired when stage i's backward has launched its last kernel
-        self._dp_rates, self._dp_seed = None, 0x0D50F7A7
+        self._dp_rates, self._dp_seed = None, ops.SWIN_DROPPATH_SEED[0]
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

@@ -689,6 +689,24 @@ def mul(a, b):
 RNG_OFFSET = [None]
 
 
+def seed_rng(seed, rank=0):
+    """Start every dropout / DropPath mask stream of the package from (seed, rank), as the reference seeds torch with `seed + rank`
+    (main_bigvul.py:536-540): data-parallel ranks then draw DIFFERENT masks for the same sample slot, and runs with different --seed
+    differ.  Without a call the streams start from fixed constants (tests rely on that)."""
+    import hashlib
+    from .models import GraphModel, unixcoder
+
+    def mix(tag):
+        h = hashlib.blake2b(f"{tag}/{int(seed)}/{int(rank)}".encode(), digest_size=8).digest()
+        return int.from_bytes(h, "little") | 1
+    GraphModel._SEED[0] = mix("head")
+    unixcoder._SEED[0] = mix("text")
+    SWIN_DROPPATH_SEED[0] = mix("swin")
+
+
+SWIN_DROPPATH_SEED = [0x0D50F7A7]          # initial DropPath stream of every SwinTransformerV2 built after this (seed_rng resets it)
+
+
 def rng_offset_ptr():
     return ptr(RNG_OFFSET[0])
 

@@ -53,12 +53,15 @@ def load_state_dict_checked(model, state_dict, logger=None, what="checkpoint"):
     return msg
 
 
-def load_checkpoint(config, model, optimizer, lr_scheduler, loss_scaler, logger):
-    logger.info(f"==============> Resuming form {config.MODEL.MULTI.RESUME}....................")
-    if config.MODEL.MULTI.RESUME.startswith('https'):
+def load_checkpoint(config, model, optimizer, lr_scheduler, loss_scaler, logger, path=None):
+    """``path``: the checkpoint file; default ``config.MODEL.MULTI.RESUME`` (the multimodal job, utils_multi.py:15-33); the Swin fine-tune
+    job passes ``config.MODEL.RESUME`` (utils.py load_checkpoint as called at main.py:162,179)."""
+    path = path or config.MODEL.MULTI.RESUME
+    logger.info(f"==============> Resuming form {path}....................")
+    if path.startswith('https'):
         raise RuntimeError("no network on this box: pass a local checkpoint path")
-    checkpoint = torch.load(config.MODEL.MULTI.RESUME, map_location='cpu', weights_only=False)
-    load_state_dict_checked(model, checkpoint['model'], logger, config.MODEL.MULTI.RESUME)
+    checkpoint = torch.load(path, map_location='cpu', weights_only=False)
+    load_state_dict_checked(model, checkpoint['model'], logger, path)
     _after_load(model)
     max_accuracy = 0.0
     epoch = checkpoint['epoch']
@@ -70,7 +73,7 @@ def load_checkpoint(config, model, optimizer, lr_scheduler, loss_scaler, logger)
         config.freeze()
         if 'scaler' in checkpoint:
             loss_scaler.load_state_dict(checkpoint['scaler'])
-        logger.info(f"=> loaded successfully '{config.MODEL.MULTI.RESUME}' (epoch {checkpoint['epoch']})")
+        logger.info(f"=> loaded successfully '{path}' (epoch {checkpoint['epoch']})")
         if 'max_accuracy' in checkpoint:
             max_accuracy = checkpoint['max_accuracy']
     del checkpoint

@@ -547,3 +547,57 @@ def test_image_ingest_tap_tables_match_oracle():
         b1, k1, s1 = pillow_bicubic_taps(n_in, n_out)
         assert s0 == s1 and np.array_equal(b0, b1) and np.array_equal(k0, k1)
         assert int(np.abs(k1.sum(1) - (1 << 22)).max()) <= k1.shape[1]           # every row sums to 1.0 in 22-bit fixed point, up to rounding
+
+
+def test_bigvul_files_dataset_reads_the_reference_file_formats(tmp_path):
+    """SURVEY section 8f row 2, the file-backed half: ``data/bigvul_dataset.BigVulFiles`` over a corpus directory in the reference's file
+    formats (image list, PNGs, Joern ``.nodes.json`` / ``.edges.json``, ``norm_pos_dict/<id>.pkl``, token-id caches; head-only mode: the
+    cached ``<id>.pt`` image features and the ``result.pkl`` frame) -- data_list.py:73-153, 265-317.  The graph of an item must be the one
+    ``joern_ingest.build_function_graph`` builds from the same export (itself pinned to the reference's pandas pipeline by
+    tests/golden/joern_cpg.json), with the OCR boxes of the pickle on the lines it names and zeros elsewhere; the image the decoded PNG;
+    the loaders the reference's signature."""
+    import json
+    import pickle
+    import numpy as np
+    import types
+    from PIL import Image
+    from mvuld_amd.config import get_config
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.data.bigvul_dataset import BigVulFiles, bigvul_loader_graph, collate
+    from mvuld_amd.data.joern_ingest import build_function_graph
+    cfg = os.path.join(ROOT, "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    root = synthetic.write_corpus(tmp_path / "corpus", {"train": [11, 12, 13, 14], "val": [21, 22], "test": [31, 32]}, seq_len=40, head_only=True)
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DATA_ROOT", root, "FUSED.SEQ_LEN", "48"], batch_size=2, local_rank=0))
+    ds = BigVulFiles(root, "train", config, fused=True)
+    assert len(ds) == 4
+    g, img, ids, label = ds[1]
+    nodes = json.load(open(os.path.join(root, "func_before", "12.c.nodes.json")))
+    edges = json.load(open(os.path.join(root, "func_before", "12.c.edges.json")))
+    pos = pickle.load(open(os.path.join(root, "norm_pos_dict", "12.pkl"), "rb"))
+    ref, code = build_function_graph(nodes, edges, pos)
+    assert torch.equal(g.src, ref.src) and torch.equal(g.dst, ref.dst) and [int(v) for v in g.batch_num_nodes()] == [int(v) for v in ref.batch_num_nodes()]
+    assert torch.equal(g.ndata["pos_emb"], ref.ndata["pos_emb"]) and torch.equal(g.edata["_ETYPE"], ref.edata["_ETYPE"])
+    ln = g.ndata["_lineno"].to(torch.int64).tolist()
+    assert any(l in pos for l in ln) and any(l not in pos for l in ln)                   # recognised and missed lines both occur
+    for k, l in enumerate(ln):
+        want = np.asarray(pos[l], dtype=np.float32) if l in pos else np.zeros(4, dtype=np.float32)
+        assert np.array_equal(g.ndata["pos_emb"][k].numpy(), want)
+    z = np.load(os.path.join(root, "line_token_ids", "12.npz"))
+    row = {int(l): k for k, l in enumerate(z["lineno"].tolist())}
+    assert g.ndata["_token_ids"].shape == (len(ln), 16) and all(np.array_equal(g.ndata["_token_ids"][k].numpy(), z["ids"][row[l]]) for k, l in enumerate(ln))
+    assert img.dtype == torch.uint8 and np.array_equal(img.numpy(), np.asarray(Image.open(os.path.join(root, "images", "12.png")).convert("RGB")))
+    raw = np.load(os.path.join(root, "token_ids", "12.npy"))
+    assert ids.shape == (48,) and np.array_equal(ids[:40].numpy(), raw) and bool((ids[40:] == 1).all())      # padded to SEQ_LEN with the pad id
+    assert label == synthetic.make_label(12)
+    gb, imgs, idb, y = collate([ds[0], ds[1]])
+    assert isinstance(imgs, list) and [int(v) for v in gb.batch_num_nodes()] == [int(ds[0][0].batch_num_nodes()[0]), int(g.batch_num_nodes()[0])]
+    assert idb.shape == (2, 48)
+    # head-only mode: the tuple ImageList.__getitem__ returns (data_list.py:141)
+    dh = BigVulFiles(root, "val", config, fused=False)
+    gh, ie, te, lh = dh[0]
+    from mvuld_amd import synth
+    assert torch.equal(ie, synth.tensor("imgfeat/21", (1024,))) and torch.allclose(te, synth.tensor("txtfeat/21", (768,)))
+    out = bigvul_loader_graph(config)
+    assert len(out) == 7 and isinstance(out[0], BigVulFiles) and len(out[1]) == 2 and len(out[2]) == 2
+    batch = next(iter(out[3]))
+    assert batch[2].shape == (2, 48) and batch[3].shape == (2,)

@@ -691,6 +691,43 @@ def test_main_bigvul_cli_end_to_end(gpu, tmp_path):
     main_bigvul.main(common + ["--test", "1"])
 
 
+def test_main_bigvul_cli_on_a_corpus_directory(gpu, tmp_path):
+    """SURVEY section 8f row 2 end to end: the reference's entry point driven from FILES -- ``FUSED.DATA_ROOT`` = a corpus directory in the
+    reference's formats (written here by data.synthetic.write_corpus: image list, PNGs of another size than the model's, Joern exports,
+    OCR pickles, token-id caches).  data/bigvul_dataset.BigVulFiles builds every graph with joern_ingest, hands over decoded uint8 images
+    (resized / normalised on the device by image_ingest) and per-line token ids (node embeddings computed on the device by the text
+    encoder: FusedMVulD.forward(node_ids=...)); one short epoch + validation + the test split must run and leave finite parameters.
+    And the device path must agree with the host path: the logits of one batch fed through model_step_inputs equal those of the same
+    model on node embeddings computed separately by encode_lines."""
+    from mvuld_amd import main_bigvul
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.data.bigvul_dataset import BigVulFiles, collate
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    root = synthetic.write_corpus(tmp_path / "corpus", {"train": list(range(40, 48)), "val": [50, 51, 52, 53], "test": [60, 61, 62, 63]},
+                                  img_hw=(150, 260), seq_len=128, vocab=1000, line_len=32, n_lines=50)
+    out, mout = str(tmp_path / "out"), str(tmp_path / "multi")
+    common = ["--cfg", cfg, "--batch-size", "2", "--output", out, "--max-steps", "3",
+              "--opts", "TRAIN.EPOCHS", "1", "FUSED.DATA_ROOT", root, "MULTI_OUTPUT", mout, "TRAIN.AUTO_RESUME", "False", "DATA.NUM_WORKERS", "0"]
+    model = main_bigvul.main(common)
+    assert bool(torch.isfinite(model._mv_store.flat).all())
+    log = "".join(open(os.path.join(dp, f)).read() for dp, _, fs in os.walk(out) for f in fs if f.startswith("log"))
+    assert "Start training" in log and "Train: [0/1]" in log
+    main_bigvul.main(common + ["--test", "1"])
+    # device-side node embeddings == encode_lines on the same ids
+    from mvuld_amd.config import get_config
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DATA_ROOT", root], batch_size=2, local_rank=0))
+    ds = BigVulFiles(root, "val", config, fused=True)
+    model.eval()
+    with torch.no_grad():
+        g, a, b, t, kw = main_bigvul.model_step_inputs(collate([ds[0], ds[1]]), gpu, image_size=config.DATA.IMG_SIZE)
+        assert "node_ids" in kw and "_UNIX_NODE_EMB" not in g.ndata
+        lg = model(g, a, b, **kw).float().cpu()
+        g2, a2, b2, _, kw2 = main_bigvul.model_step_inputs(collate([ds[0], ds[1]]), gpu, image_size=config.DATA.IMG_SIZE)
+        g2.ndata["_UNIX_NODE_EMB"] = model.unixcoder.encode_lines(kw2.pop("node_ids"), kw2.pop("node_lens")).float()
+        lg2 = model(g2, a2, b2, **kw2).float().cpu()
+    assert torch.isfinite(lg).all() and float((lg - lg2).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_fused_full_size_eval_logits_vs_oracle(gpu, dtype):
     """north_star at its named size: SwinV2-base 448^2 (window 28) + 12-layer UniXcoder at 512 tokens + head, 2 functions, eval mode,
@@ -718,6 +755,71 @@ def test_fused_full_size_eval_logits_vs_oracle(gpu, dtype):
     err = float((logits - ref).abs().max())
     print(f"[fused full size, {dtype} eval] logits abs err {err:.3e} (logit scale {float(ref.abs().max()):.3f})")
     assert err < (1e-3 if dtype == torch.float32 else 1e-2)
+
+
+def test_fused_headline_batch32_eval_and_gradient(gpu):
+    """BASELINE configs[1] at its stated batch: 32 functions per GPU, full size (448^2 images, 512-token rows, 150-250-node graphs), bf16.
+    M = 401 408 image tokens selects other GEMM tile plans and attention launch shapes than the oracle-checked 2-function case, so:
+    (i) the eval logits of functions {0, 15, 31} inside the batch of 32 must equal the same functions run as a batch of 2 (whose logits
+    are pinned to the fp32 oracle by test_fused_full_size_eval_logits_vs_oracle) -- every kernel accumulates a row's contraction in the
+    same order whatever the batch, so the bound is a few bf16 roundings of the logit scale;
+    (ii) one backward at batch 32 (eval-mode BatchNorm statistics, dropouts off: no coupling across the batch) must give the flat
+    gradient buffer that four batches of 8 of the same functions give on average, to the noise of their different split-K / atomic
+    orders."""
+    from mvuld_amd.config import get_config
+    from mvuld_amd.main_bigvul import build_fused_model
+    from mvuld_amd.models.GraphModel import cross_entropy
+    from mvuld_amd.optimizer import build_optimizer
+    from mvuld_amd.data import synthetic
+    from mvuld_amd.graph import batch as gbatch, unbatch
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin",
+                       "swinv2_base_patch4_window24to28_384to448_1ktoMYDATA_ft.yaml")
+    config = get_config(types.SimpleNamespace(cfg=cfg, opts=["FUSED.DTYPE", "bf16"], batch_size=32, local_rank=0))
+    model = build_fused_model(config)
+    load_synth_into(model)
+    model = model.to(gpu).eval()
+    opt = build_optimizer(config, model)
+    f = config.FUSED
+    seeds = list(range(100, 132))
+    g, images, ids, labels = synthetic.make_batch(seeds, config.DATA.IMG_SIZE, f.SEQ_LEN, f.TEXT.VOCAB, f.NODES_LO, f.NODES_HI)
+    graphs = unbatch(g)
+
+    def sub(idx):
+        gg = gbatch([graphs[i] for i in idx])
+        gg.index()
+        return gg.to(gpu), images[idx].to(gpu), ids[idx].to(gpu), labels[idx].to(gpu)
+    g.index()
+    with torch.no_grad():
+        big = model(g.to(gpu), images.to(gpu), ids.to(gpu)).float().cpu()
+        pick = [0, 15, 31]
+        small = torch.cat([model(*sub([i, (i + 1) % 32])[:3]).float().cpu()[:1] for i in pick])
+    scale = float(big.abs().max())
+    err = float((big[pick] - small).abs().max())
+    print(f"[batch 32 vs batch 2] logits abs diff {err:.3e} (logit scale {scale:.3f})")
+    assert err < 2e-3 * max(1.0, scale)
+    # (ii) gradients
+    store = model._mv_store
+    opt.zero_grad()
+    lg = model(g.to(gpu), images.to(gpu), ids.to(gpu))
+    loss, _ = cross_entropy(lg, labels.to(gpu))
+    loss.backward()
+    from mvuld_amd import ops
+    ops.join_grad_streams()
+    torch.cuda.synchronize()
+    g32 = store.grad.clone()
+    acc = torch.zeros_like(g32)
+    for k in range(4):
+        opt.zero_grad()
+        gg, im, tx, lb = sub(list(range(8 * k, 8 * k + 8)))
+        l8, _ = cross_entropy(model(gg, im, tx), lb)
+        l8.backward()
+        ops.join_grad_streams()
+        torch.cuda.synchronize()
+        acc += store.grad
+    acc /= 4
+    e = float((g32 - acc).norm() / acc.norm())
+    print(f"[batch 32 gradient vs mean of 4 x batch 8] rel l2 {e:.3e}, |g| {float(acc.norm()):.3e}, loss {float(loss.detach()):.4f}")
+    assert e < 2e-2 and bool(torch.isfinite(g32).all())
 
 
 def test_fused_full_size_fp8_eval_logits_vs_oracle(gpu):
@@ -968,6 +1070,85 @@ def test_swin_finetune_driver_cli(gpu, tmp_path):
     assert len(res) == 4 and all(np.isfinite(v) for v in res)
     tput = swin_main.main(common + ["--throughput"])
     assert tput > 0
+
+
+def test_swin_finetune_resume_restores_training_state(gpu, tmp_path, monkeypatch):
+    """main.py:146-181: a run that finds a best-F1 checkpoint under OUTPUT (TRAIN.BEST_RESUME) continues from it -- model, AdamW moments and
+    step count, LR schedule, START_EPOCH, max_accuracy (load_checkpoint) -- instead of restarting at epoch 0 with a fresh optimizer.  Run 1
+    trains one epoch of 3 steps (validation patched to report F1 = 1 so the checkpoint is written); run 2 (2 epochs) must enter
+    train_one_epoch first with epoch 1 and an optimizer that has already taken 3 steps and carries non-zero moments."""
+    from mvuld_amd import main as swin_main
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mvuld_amd", "configs", "mySwin", "tiny_plumbing.yaml")
+    out = str(tmp_path / "out")
+    common = ["--cfg", cfg, "--batch-size", "2", "--output", out, "--max-steps", "3",
+              "--opts", "FUSED.SYNTH_TRAIN", "8", "FUSED.SYNTH_VAL", "4", "FUSED.SYNTH_TEST", "4", "TRAIN.AUTO_RESUME", "False", "TRAIN.WARMUP_EPOCHS", "0"]
+    monkeypatch.setattr(swin_main, "validate", lambda *a, **k: (50.0, 0.5, 1.0, 1.0))
+    swin_main.main(common + ["TRAIN.EPOCHS", "1"])
+    import glob
+    assert glob.glob(os.path.join(out, "**", "checkpoint-best-f1", "mymodel.pth"), recursive=True)       # OUTPUT/<model name>/<tag>/...
+    seen = []
+    real = swin_main.train_one_epoch
+
+    def spy(config, model, loader, optimizer, epoch, *a, **k):
+        seen.append((epoch, optimizer._step, float(optimizer.store.exp_avg.abs().sum())))
+        return real(config, model, loader, optimizer, epoch, *a, **k)
+    monkeypatch.setattr(swin_main, "train_one_epoch", spy)
+    swin_main.main(common + ["TRAIN.EPOCHS", "2"])
+    assert seen and seen[0][0] == 1 and seen[0][1] == 3, seen
+    assert seen[0][2] > 0
+
+
+def test_mixup_cutmix_and_soft_target_cross_entropy(gpu):
+    """the Swin fine-tune job's augmentation-side loss (main.py:136-140, 268-269).  mvuld_mixup_batch (timm Mixup,
+    "batch" mode: partner = the reversed batch; mixup blend or cutmix box paste; label-smoothed mixed targets) and
+    mvuld_cross_entropy_soft (SoftTargetCrossEntropy / LabelSmoothingCrossEntropy, loss + probabilities + gradient) against torch
+    restatements of timm's formulas; the host-side parameter draws follow timm's call order on numpy's global generator."""
+    from mvuld_amd.data.mixup import Mixup
+    from mvuld_amd.models.GraphModel import label_smoothing_cross_entropy, soft_target_cross_entropy
+    B, C, H, W, K = 6, 3, 20, 28, 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    y = torch.randint(0, K, (B,), generator=g)
+
+    def onehot(t, smoothing):
+        off = smoothing / K
+        return torch.full((B, K), off).scatter_(1, t.view(-1, 1), 1.0 - smoothing + off)
+    for seed, (ma, ca) in enumerate([(0.8, 1.0), (0.8, 0.0), (0.0, 1.0), (0.8, 1.0), (0.8, 1.0)]):
+        np.random.seed(100 + seed)
+        m = Mixup(mixup_alpha=ma, cutmix_alpha=ca, prob=1.0, switch_prob=0.5, label_smoothing=0.1, num_classes=K)
+        lam, cut, (yl, yh, xl, xh) = m.draw(x.shape)
+        np.random.seed(100 + seed)                      # the same draws again inside __call__
+        for dtype in (torch.float32, torch.bfloat16):
+            xs = x.to(dtype)
+            out, soft = m(xs.to(gpu), y.to(gpu))
+            np.random.seed(100 + seed)
+            if cut:
+                ref = xs.clone()
+                ref[:, :, yl:yh, xl:xh] = xs.flip(0)[:, :, yl:yh, xl:xh]
+                assert abs(lam - (1.0 - (yh - yl) * (xh - xl) / float(H * W))) < 1e-12
+            else:
+                ref = (xs.float() * lam + xs.float().flip(0) * (1.0 - lam)).to(dtype)
+            assert torch.equal(out.cpu(), ref) if cut else rel(out, ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+            tref = onehot(y, 0.1) * lam + onehot(y.flip(0), 0.1) * (1.0 - lam)
+            assert rel(soft, tref) < 1e-6
+    # criteria
+    logits = torch.randn(B, K, generator=g) * 2
+    tsoft = onehot(y, 0.1) * 0.3 + onehot(y.flip(0), 0.1) * 0.7
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.sum(-tsoft * F.log_softmax(lr, dim=-1), dim=-1).mean()            # timm SoftTargetCrossEntropy
+    ref.backward()
+    lg = logits.to(gpu).requires_grad_(True)
+    loss, probs = soft_target_cross_entropy(lg, tsoft.to(gpu), loss_scale=0.5)
+    (loss * 3.0).backward()
+    assert abs(float(loss) - 0.5 * float(ref)) < 1e-6 and rel(probs, F.softmax(logits, -1)) < 1e-6 and rel(lg.grad, 1.5 * lr.grad) < 1e-5
+    lr = logits.clone().requires_grad_(True)
+    lp = F.log_softmax(lr, dim=-1)                                                    # timm LabelSmoothingCrossEntropy(smoothing=0.1)
+    ref = (0.9 * (-lp.gather(1, y.view(-1, 1)).squeeze(1)) + 0.1 * (-lp.mean(-1))).mean()
+    ref.backward()
+    lg = logits.to(gpu).requires_grad_(True)
+    loss, _ = label_smoothing_cross_entropy(lg, y.to(gpu), 0.1)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-6 and rel(lg.grad, lr.grad) < 1e-5
 
 
 def test_graphed_train_step_matches_eager(gpu):
