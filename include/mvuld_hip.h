@@ -104,6 +104,19 @@ int mvuld_set_gemm_p256_k64(int on);
  * Bit-identical results; initialised from MVULD_P256_EARLY. */
 int mvuld_set_gemm_p256_early(int on);
 
+/* Fused MLP of the narrow Swin stages (Mlp.forward, swin_transformer_v2.py:26-32, and its autograd), C = 128 / 256, bf16, hidden = 4C:
+ * at these widths the MLP's products are HBM streams; these two kernels keep the hidden dimension on the chip (csrc/mlp_panel.hip).
+ *   fwd: y [M, C] = gelu(x W1^T + b1) W2^T + b2 and the activation h [M, 4C] (the fc2 weight gradient reads it; null = not
+ *        written: inference); no pre-activation.
+ *   bwd: dh [M, 4C] = (dy W2) o gelu'(x W1^T + b1) (pre-activation recomputed; the fc1 weight gradient reads dh) and
+ *        dx [M, C] = dh W1 + g (g: residual gradient, may be null).  w2t = fc2.weight^T [4C, C], w1t = fc1.weight^T [C, 4C].
+ * Same values as mvuld_gemm_nt with the GELU / dGELU / residual-join epilogues up to bf16 rounding of the stored intermediates
+ * (the recomputed pre-activation is fp32 here, bf16 there).  All operands 16-byte aligned, row-major, leading dimension = width. */
+int mvuld_mlp_fused_supported(int C);
+int mvuld_mlp_fused_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* h, void* y, int M, int C,
+                        mvuld_stream_t stream);
+int mvuld_mlp_fused_bwd(const void* x, const void* dy, const void* g, const void* w1, const float* b1, const void* w2t, const void* w1t,
+                        void* dh, void* dx, int M, int C, mvuld_stream_t stream);
 /* Weight gradient on the matrix cores without transposes: dW[N,K] += dY[M,N]^T . X[M,K] (bf16 operands in their token-major
  * layout, fp32 accumulate); dbias[N] += column sums of dY when non-null.  The token contraction is split over workgroups.
  * `ws` (optional, caller-owned, ws_bytes >= mvuld_gemm_tn_wgrad_workspace_bytes(M, N, K, splitk), 16-byte aligned, ZEROED ONCE by

@@ -97,8 +97,12 @@ class _SwinBlockFn(torch.autograd.Function):
         x1, mean1, rstd1, _, x1q = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x, rowscale=rowscale,
                                                      rows_per_sample=L, emit=ops.fp8_site(blk, "x1", x.device) if fp8 else False)
         # the pre-activation is kept for dGELU only: inference skips that write (and, in fp8, the bf16 copy of the activation too)
-        hpre = torch.empty((x.shape[0], blk.mlp.fc1.weight.shape[0]), dtype=ad, device=x.device) if need_bwd else None
-        if fp8:
+        fused_mlp = (not fp8) and ops.mlp_fused_ok(x1, blk.mlp.fc1.weight, training=need_bwd)
+        hpre = torch.empty((x.shape[0], blk.mlp.fc1.weight.shape[0]), dtype=ad, device=x.device) if (need_bwd and not fused_mlp) else None
+        if fused_mlp:
+            # C = 128 / 256 (stages 0 and 1): fc1 + GELU + fc2 in one kernel, hidden on the chip; backward recomputes the pre-activation
+            hact, m = ops.mlp_fused_fwd(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, need_h=need_bwd)
+        elif fp8:
             hact, hq = ops.linear_fwd(x1, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre, xq=x1q,
                                       emit=ops.fp8_site(blk, "h", x.device), need_out=need_bwd)
             m = ops.linear_fwd(hact, blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias.data, xq=hq)
@@ -131,9 +135,13 @@ class _SwinBlockFn(torch.autograd.Function):
         # ---- FFN branch: x2 = x1 + rs * LN(m)
         dm = ops.layernorm_bwd(g, m, blk.norm2.weight, blk.norm2.bias, mean2, rstd2, rowscale, L)
         ops.linear_wgrad(dm, hact, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        dhpre = ops.gemm_nt(dm, ops.weight_t(blk.mlp.fc2.weight, ad), epi=hip.EPI_MUL_DGELU, aux=hpre)
-        ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
-        g1 = ops.gemm_nt(dhpre, ops.weight_t(blk.mlp.fc1.weight, ad), epi=hip.EPI_ADD_AUX, aux=g)
+        if hpre is None:        # fused MLP: d(pre-activation) and the block-input gradient in one kernel (pre-activation recomputed)
+            dhpre, g1 = ops.mlp_fused_bwd(x1, dm, g, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight)
+            ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        else:
+            dhpre = ops.gemm_nt(dm, ops.weight_t(blk.mlp.fc2.weight, ad), epi=hip.EPI_MUL_DGELU, aux=hpre)
+            ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+            g1 = ops.gemm_nt(dhpre, ops.weight_t(blk.mlp.fc1.weight, ad), epi=hip.EPI_ADD_AUX, aux=g)
         # ---- attention branch: x1 = x + rs * LN(proj)
         dproj = ops.layernorm_bwd(g1, proj, blk.norm1.weight, blk.norm1.bias, mean1, rstd1, rowscale, L)
         ops.linear_wgrad(dproj, att, a.proj.weight, a.proj.bias)

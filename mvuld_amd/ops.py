@@ -375,6 +375,44 @@ def linear_fwd(x, w_param, bias=None, epi=hip.EPI_NONE, aux=None, xq=None, emit=
     return (out, None) if emit is not None else out
 
 
+# fused MLP (csrc/mlp_panel.hip): widest block width that takes it -- 0 = never, 128 (default) = Swin stage 0, 256 = stages 0 and 1
+FUSED_MLP_MAX_C = [int(os.environ.get("MVULD_FUSED_MLP", "128"))]
+FUSED_MLP_TRAIN = [os.environ.get("MVULD_FUSED_MLP_TRAIN", "1") != "0"]      # also in training (forward + recomputing backward)
+
+
+def mlp_fused_ok(x, fc1_w, training=False):
+    """The fused MLP kernels take bf16 blocks of width 128 / 256 with hidden = 4C (Swin stages 0 and 1).  Measured (tools/bench_mlp.py,
+    DESIGN section 9c): the forward wins at C = 128 (263 vs 363 us, less without the activation copy: inference), the recomputing backward
+    about breaks even (427 vs 403 us) and C = 256 loses on both (259 vs 215, 368 vs 215 us) -- the default is C = 128 only, in training
+    (step 55.63 -> 55.29 ms) and inference (batch 256: 113.3 -> 111.5 ms)."""
+    C = x.shape[1]
+    if training and not FUSED_MLP_TRAIN[0]:
+        return False
+    return (C <= FUSED_MLP_MAX_C[0] and x.is_cuda and x.dtype == torch.bfloat16 and not FORCE_SIMPLE_GEMM[0] and x.is_contiguous()
+            and tuple(fc1_w.shape) == (4 * C, C) and bool(hip.LIB.fn("mvuld_mlp_fused_supported")(C)))
+
+
+def mlp_fused_fwd(x, fc1_w, fc1_b, fc2_w, fc2_b, need_h=True):
+    """-> (h = gelu(x W1^T + b1) [M, 4C] (None without need_h), y = h W2^T + b2 [M, C]); the pre-activation is never written."""
+    M, C = x.shape
+    h = torch.empty((M, 4 * C), dtype=x.dtype, device=x.device) if need_h else None
+    y = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    hip.TIMING.annotate("gemm_nt_mfma_bf16", 2.0 * 2.0 * M * C * 4 * C)
+    call("mlp_fused_fwd", ptr(x), ptr(weight(fc1_w, x.dtype)), ptr(fc1_b.data), ptr(weight(fc2_w, x.dtype)), ptr(fc2_b.data), ptr(h), ptr(y), M, C)
+    return h, y
+
+
+def mlp_fused_bwd(x, dy, g, fc1_w, fc1_b, fc2_w):
+    """-> (dh = (dy W2) o gelu'(x W1^T + b1) [M, 4C], dx = dh W1 + g [M, C])."""
+    M, C = x.shape
+    dh = torch.empty((M, 4 * C), dtype=x.dtype, device=x.device)
+    dx = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    hip.TIMING.annotate("gemm_nt_mfma_bf16", 3.0 * 2.0 * M * C * 4 * C)
+    call("mlp_fused_bwd", ptr(x), ptr(dy), ptr(g), ptr(weight(fc1_w, x.dtype)), ptr(fc1_b.data), ptr(weight_t(fc2_w, x.dtype)),
+         ptr(weight_t(fc1_w, x.dtype)), ptr(dh), ptr(dx), M, C)
+    return dh, dx
+
+
 def transpose(x, R=None, C=None, batch=1, out=None):
     R = x.shape[-2] if R is None else R
     C = x.shape[-1] if C is None else C

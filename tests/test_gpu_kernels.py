@@ -879,6 +879,50 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(1)
 
 
+@pytest.mark.parametrize("M,C", [(6272, 128), (1000, 128), (3136, 256), (777, 256), (70000, 128)])
+def test_fused_mlp_panel_kernels(gpu, M, C):
+    """Round 3, csrc/mlp_panel.hip (Mlp.forward swin_transformer_v2.py:26-32 and its autograd at C = 128 / 256): the fused forward
+    y = gelu(x W1^T + b1) W2^T + b2 (+ the activation, no pre-activation) and the fused backward dh = (dy W2) o gelu'(x W1^T + b1),
+    dx = dh W1 + g against (a) fp32 torch on the bf16-rounded operands and (b) the three unfused GEMM launches they replace; row counts
+    that are not multiples of the 128 / 256-row panels (clamped rows duplicate row M - 1), panels over several workgroup rounds."""
+    from mvuld_amd import ops, hip
+    g_ = torch.Generator().manual_seed(31 + C)
+    bf = torch.bfloat16
+    x = (torch.randn(M, C, generator=g_) * 0.8).to(bf)
+    dy = torch.randn(M, C, generator=g_).to(bf)
+    gres = torch.randn(M, C, generator=g_).to(bf)
+    w1 = torch.nn.Parameter(torch.randn(4 * C, C, generator=g_) * C ** -0.5)
+    b1 = torch.nn.Parameter(torch.randn(4 * C, generator=g_) * 0.3)
+    w2 = torch.nn.Parameter(torch.randn(C, 4 * C, generator=g_) * (4 * C) ** -0.5)
+    b2 = torch.nn.Parameter(torch.randn(C, generator=g_) * 0.3)
+    W1, B1, W2, B2 = (torch.nn.Parameter(t.detach().to(gpu)) for t in (w1, b1, w2, b2))
+    X, DY, G = x.to(gpu), dy.to(gpu), gres.to(gpu)
+    assert bool(hip.LIB.fn("mvuld_mlp_fused_supported")(C))
+    h, y = ops.mlp_fused_fwd(X, W1, B1, W2, B2)
+    w1r, w2r = w1.detach().to(bf).float(), w2.detach().to(bf).float()
+    pre = x.float() @ w1r.t() + b1.detach()
+    h_ref = F.gelu(pre)
+    y_ref = h_ref.to(bf).float() @ w2r.t() + b2.detach()
+    assert rel(h, h_ref) < 1e-2 and rel(y, y_ref) < 1e-2, (rel(h, h_ref), rel(y, y_ref))
+    _, y2 = ops.mlp_fused_fwd(X, W1, B1, W2, B2, need_h=False)
+    assert torch.equal(y2, y)
+    dh, dx = ops.mlp_fused_bwd(X, DY, G, W1, B1, W2)
+    pr = pre.clone().requires_grad_(True)
+    F.gelu(pr).sum().backward()
+    dh_ref = (dy.float() @ w2r) * pr.grad
+    dx_ref = dh_ref.to(bf).float() @ w1r + gres.float()
+    assert rel(dh, dh_ref) < 1e-2 and rel(dx, dx_ref) < 1e-2, (rel(dh, dh_ref), rel(dx, dx_ref))
+    _, dx0 = ops.mlp_fused_bwd(X, DY, None, W1, B1, W2)
+    assert rel(dx0, dh_ref.to(bf).float() @ w1r) < 1e-2
+    # the unfused launches
+    hpre = torch.empty((M, 4 * C), dtype=bf, device=gpu)
+    hu = ops.gemm_nt(X, ops.weight(W1, bf), bias=B1.data, epi=hip.EPI_GELU, aux=hpre)
+    yu = ops.gemm_nt(hu, ops.weight(W2, bf), bias=B2.data)
+    dhu = ops.gemm_nt(DY, ops.weight_t(W2, bf), epi=hip.EPI_MUL_DGELU, aux=hpre)
+    dxu = ops.gemm_nt(dhu, ops.weight_t(W1, bf), epi=hip.EPI_ADD_AUX, aux=G)
+    assert rel(h, hu) < 8e-3 and rel(y, yu) < 8e-3 and rel(dh, dhu) < 1.5e-2 and rel(dx, dxu) < 1.5e-2, (rel(h, hu), rel(y, yu), rel(dh, dhu), rel(dx, dxu))
+
+
 @pytest.mark.parametrize("M,shapes", [(6272, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),          # a Swin stage-2 block (fc2, fc1, proj, qkv)
                                       (9917, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),          # a RoBERTa layer on a ragged packed token count
                                       (3136, [(1024, 4096), (4096, 1024), (384, 128), (1024, 1024), (3072, 1024)])])   # stage 3 + one ineligible product
