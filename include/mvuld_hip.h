@@ -160,6 +160,11 @@ int mvuld_colsum(const void* x, int64_t ld, float* out, int64_t M, int N, int dt
 int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta,
                         const void* residual, const float* rowscale, int rows_per_sample, void* y, float* mean,
                         float* rstd, int64_t rows, int C, float eps, int dtype, mvuld_stream_t stream);
+/* y = LayerNorm(dropout(x, p) + pre) * gamma + beta with mvuld_dropout's mask (same seed / counter: bit-identical to mvuld_dropout followed by
+ * mvuld_layernorm_fwd), bf16 only: the hidden-state dropouts of RobertaSelfOutput / RobertaOutput (HF modeling_roberta) in one pass. */
+int mvuld_layernorm_fwd_drop(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, void* y, float* mean,
+                             float* rstd, int64_t rows, int C, float eps, float drop_p, uint64_t drop_seed, const uint64_t* seed_offset,
+                             mvuld_stream_t stream);
 /* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta accumulate (+=).  `ws` (optional, fp32,
  * ws_bytes >= 512*C) lends room for per-block column partials summed by a second kernel; without it the column sums
  * are device atomics (slower: ~1.5M contended atomics per launch at C=768). */

@@ -37,6 +37,12 @@ __device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
 template <typename T>
 __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
 
+// counter-based 32-bit hash of a 64-bit counter: the element masks of mvuld_dropout (and of the LayerNorm that fuses it)
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

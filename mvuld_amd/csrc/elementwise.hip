@@ -211,10 +211,6 @@ extern "C" int mvuld_mul(const void* a, const void* b, void* y, int64_t n, int d
 }
 
 // ------------------------------------------------------------------------------------ dropout (counter-based, recomputable)
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-    return (uint32_t)x;
-}
 // y = x * keep(i) / (1-p), keep(i) = hash(seed, i) >= p.  Same call on the gradient in backward.
 // seed_off (optional): one uint64 on the device added to the host seed -- a step counter that lives in device memory, so that a
 // hipGraph replay of a captured training step draws fresh masks (the host seed is frozen into the captured kernel arguments).

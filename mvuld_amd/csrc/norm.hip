@@ -138,13 +138,19 @@ __device__ __forceinline__ float group_sum(float v, int G) {
     return v;
 }
 
-template <int CPL, bool HAS_PRE, bool HAS_RES>
+// DROP (with HAS_PRE): x is first put through mvuld_dropout's mask -- bf16(keep ? x / (1 - p) : 0), element counter row * C + column,
+// the same bits the separate kernel would have written -- so RoBERTa's LayerNorm(dropout(dense) + input) is one pass over the rows
+template <int CPL, bool HAS_PRE, bool HAS_RES, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restrict__ x, const bf16* __restrict__ pre, bf16* __restrict__ xsum,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const bf16* __restrict__ res, const float* __restrict__ rowscale,
                                                            int rows_per_sample, bf16* __restrict__ y, float* __restrict__ mean,
                                                            float* __restrict__ rstd, int64_t rows, int C, int G, float eps,
-                                                           uint2* __restrict__ q8, float* __restrict__ qstate) {
+                                                           uint2* __restrict__ q8, float* __restrict__ qstate, float drop_p = 0.f,
+                                                           uint64_t drop_seed = 0, const uint64_t* __restrict__ drop_off = nullptr) {
+    if (DROP && drop_off) drop_seed += drop_off[0] * 0xD1B54A32D192ED03ULL;
+    const float drop_inv = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uint32_t drop_thr = DROP ? (uint32_t)(drop_p * 4294967296.0) : 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane & (G - 1), rg = lane / G, rpw = 64 / G;
     const int nch = C >> 3;
@@ -184,6 +190,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float t = (float)a[i].v[e];
+                if (DROP) {
+                    const bool keep = mix32(drop_seed + (uint64_t)(rc * C + chc[i] * 8 + e) * 0x9E3779B97F4A7C15ULL) >= drop_thr;
+                    t = (float)(bf16)(keep ? t * drop_inv : 0.f);
+                }
                 if (HAS_PRE) { t += (float)p[i].v[e]; a[i].v[e] = (bf16)t; t = (float)a[i].v[e]; }
                 t = chok[i] ? t : 0.f;
                 v[i][e] = t;
@@ -426,6 +436,28 @@ extern "C" int mvuld_layernorm_fwd_q8(const void* x, const void* pre, void* xsum
                                       int64_t rows, int C, float eps, void* q_out, float* q_state, hipStream_t stream) {
     MV_CHECK_ARG(q_out && q_state && (((uintptr_t)q_out) & 7) == 0, "layernorm_fwd_q8: null / misaligned e4m3 output");
     return layernorm_fwd_impl(x, pre, xsum, gamma, beta, residual, rowscale, rows_per_sample, y, mean, rstd, rows, C, eps, MVULD_BF16, q_out, q_state, stream);
+}
+
+// LayerNorm(dropout(x) + pre): mvuld_dropout(x, p, seed) fused into the post-LN of the text encoder (bf16, C % 8 == 0, 16-byte aligned);
+// bit-identical to the two separate launches
+extern "C" int mvuld_layernorm_fwd_drop(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, void* y, float* mean,
+                                        float* rstd, int64_t rows, int C, float eps, float drop_p, uint64_t drop_seed, const uint64_t* seed_offset,
+                                        hipStream_t stream) {
+    MV_CHECK_ARG(x && pre && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * LN_MAXPL, "layernorm_fwd_drop: bad args (rows=%lld C=%d)", (long long)rows, C);
+    MV_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "layernorm_fwd_drop: 0 <= p < 1");
+    MV_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)pre | (uintptr_t)xsum | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd_drop: 16-byte aligned tensors only");
+    const int G = ln_group(C), rpw = 64 / G;
+    const int gridv = (int)min((int64_t)4096, cdiv(rows, (int64_t)4 * rpw));
+    if (C / 8 <= G)
+        hipLaunchKernelGGL((layernorm_fwd_vec_k<1, true, false, true>), dim3(gridv), dim3(256), 0, stream, (const bf16*)x, (const bf16*)pre, (bf16*)xsum,
+                           gamma, beta, (const bf16*)nullptr, (const float*)nullptr, 1, (bf16*)y, mean, rstd, rows, C, G, eps, (uint2*)nullptr, (float*)nullptr,
+                           drop_p, drop_seed, seed_offset);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_vec_k<2, true, false, true>), dim3(gridv), dim3(256), 0, stream, (const bf16*)x, (const bf16*)pre, (bf16*)xsum,
+                           gamma, beta, (const bf16*)nullptr, (const float*)nullptr, 1, (bf16*)y, mean, rstd, rows, C, G, eps, (uint2*)nullptr, (float*)nullptr,
+                           drop_p, drop_seed, seed_offset);
+    MV_LAUNCH_CHECK("layernorm_fwd_drop");
+    return 0;
 }
 
 extern "C" int mvuld_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,

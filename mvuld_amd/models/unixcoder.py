@@ -237,9 +237,13 @@ class _LayerFn(torch.autograd.Function):
         cx, lse = ops.attn_fwd(geom, qkv, valid=valid)
         ao = layer.attention.output
         a = ops.gemm_nt(cx, ops.weight(ao.dense.weight, ad), bias=ao.dense.bias.data)
-        a = ops.dropout(a, ph, seeds[1])
-        x1, mean1, rstd1, s1, x1q = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x,
-                                                      want_sum=True, emit=ops.fp8_site(layer, "x1", x.device) if fp8 else False)
+        if ph > 0.0 and not fp8:          # hidden dropout inside the LayerNorm's pass (same mask / bits as the separate launch)
+            x1, mean1, rstd1, s1 = ops.layernorm_dropout_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps, x, ph, seeds[1])
+            x1q = None
+        else:
+            a = ops.dropout(a, ph, seeds[1])
+            x1, mean1, rstd1, s1, x1q = ops.layernorm_fwd(a, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x,
+                                                          want_sum=True, emit=ops.fp8_site(layer, "x1", x.device) if fp8 else False)
         it, ot = layer.intermediate, layer.output
         ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device) if need_bwd else None
         if fp8:
@@ -249,10 +253,14 @@ class _LayerFn(torch.autograd.Function):
         else:
             iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
             o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
-        o = ops.dropout(o, ph, seeds[2])
-        x2, mean2, rstd2, s2, x2q = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x1,
-                                                      want_sum=True,
-                                                      emit=ops.fp8_site(layer, "x2", x.device) if (fp8 and getattr(layer, "_q8_next", False)) else False)
+        if ph > 0.0 and not fp8:
+            x2, mean2, rstd2, s2 = ops.layernorm_dropout_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps, x1, ph, seeds[2])
+            x2q = None
+        else:
+            o = ops.dropout(o, ph, seeds[2])
+            x2, mean2, rstd2, s2, x2q = ops.layernorm_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps, pre=x1,
+                                                          want_sum=True,
+                                                          emit=ops.fp8_site(layer, "x2", x.device) if (fp8 and getattr(layer, "_q8_next", False)) else False)
         ops.fp8_put(x2, x2q)                # the next layer's QKV product takes it
         ctx.save_for_backward(x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2)
         ctx.layer, ctx.geom, ctx.hdrop = layer, geom, (ph, seeds[1], seeds[2])

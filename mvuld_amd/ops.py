@@ -670,6 +670,25 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, residual=None, rowscale=None, rows_p
     return y, mean, rstd, xsum
 
 
+USE_LN_DROP = [os.environ.get("MVULD_LN_DROP", "1") != "0"]
+
+
+def layernorm_dropout_fwd(x, gamma, beta, eps, pre, p, seed, want_sum=True):
+    """LayerNorm(dropout(x, p, seed) + pre): the hidden-state dropout of the text encoder's post-LN blocks in the LayerNorm's own pass
+    (mvuld_layernorm_fwd_drop: same mask, same bits as dropout() followed by layernorm_fwd()).  -> (y, mean, rstd, xsum)."""
+    rows, C = x.shape
+    if not (USE_LN_DROP[0] and p > 0.0 and x.dtype == torch.bfloat16 and C % 8 == 0 and x.is_contiguous() and pre.is_contiguous()):
+        y, mean, rstd, xsum = layernorm_fwd(dropout(x, p, seed), gamma, beta, eps, pre=pre, want_sum=want_sum)[:4]
+        return y, mean, rstd, xsum
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    xsum = torch.empty_like(x) if want_sum else None
+    call("layernorm_fwd_drop", ptr(x), ptr(pre), ptr(xsum), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, C, eps, float(p),
+         int(seed) & 0xFFFFFFFFFFFFFFFF, rng_offset_ptr())
+    return y, mean, rstd, xsum
+
+
 def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sample=1):
     rows, C = x.shape
     dx = torch.empty_like(x)

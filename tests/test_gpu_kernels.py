@@ -879,6 +879,27 @@ def test_gemm_tn_wgrad(gpu, M, N, K, mode):
         hip.LIB.fn("mvuld_set_gemm_tn256_pingpong")(1)
 
 
+@pytest.mark.parametrize("rows,C", [(1000, 768), (333, 128), (4096, 1024)])
+def test_layernorm_with_fused_hidden_dropout_is_bit_identical(gpu, rows, C):
+    """mvuld_layernorm_fwd_drop = LayerNorm(dropout(x) + pre) in one pass (RobertaSelfOutput / RobertaOutput: dense -> dropout -> LayerNorm(+
+    input)) must reproduce mvuld_dropout followed by mvuld_layernorm_fwd bit for bit: same counter hash, same bf16 rounding points."""
+    from mvuld_amd import ops
+    g_ = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g_).to(torch.bfloat16).to(gpu)
+    pre = torch.randn(rows, C, generator=g_).to(torch.bfloat16).to(gpu)
+    gamma, beta = (torch.rand(C, generator=g_) + 0.5).to(gpu), torch.randn(C, generator=g_).to(gpu)
+    for p, seed in ((0.1, 12345), (0.5, 7)):
+        ops.USE_LN_DROP[0] = True
+        y1, m1, r1, s1 = ops.layernorm_dropout_fwd(x, gamma, beta, 1e-5, pre, p, seed)
+        ops.USE_LN_DROP[0] = False
+        try:
+            y0, m0, r0, s0 = ops.layernorm_dropout_fwd(x, gamma, beta, 1e-5, pre, p, seed)
+        finally:
+            ops.USE_LN_DROP[0] = True
+        assert torch.equal(y1, y0) and torch.equal(s1, s0) and torch.equal(m1, m0) and torch.equal(r1, r0)
+        assert not torch.equal(s1, (x.float() + pre.float()).to(torch.bfloat16))          # the mask did something
+
+
 @pytest.mark.parametrize("M,C", [(6272, 128), (1000, 128), (3136, 256), (777, 256), (70000, 128)])
 def test_fused_mlp_panel_kernels(gpu, M, C):
     """Round 3, csrc/mlp_panel.hip (Mlp.forward swin_transformer_v2.py:26-32 and its autograd at C = 128 / 256): the fused forward
