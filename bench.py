@@ -190,7 +190,7 @@ def main():
         tt = torch.tensor([dt], device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     n_fn = args.batch * world_size() * args.steps
     value = n_fn / dt
     ms_per_step = dt / args.steps * 1e3

@@ -238,16 +238,28 @@ struct TnJob {
     int64_t ldy, ldx, ldw;
     int M, N, K, tiles_k, nsplit, per, wg0, slab0;       // wg0: first workgroup of the product; slab0: its first slab in the workspace
 };
-struct TnJobs { int n, wg_total, tiles_total, pad; int tile0[TN_MAX_JOBS + 1]; TnJob j[TN_MAX_JOBS]; };
+// map[g] = product << 12 | workgroup index inside the product, for launch-order block g.  Blocks g, g + 8, ... share an XCD and its L2 (observed
+// placement, used for speed only): the host deals the blocks so that all tiles of one (product, token split) sit on ONE XCD -- they walk the same 32-token
+// slabs of dY and X at the same time, so each operand row is fetched from HBM once per XCD instead of once per tile (tiles_n + tiles_k times:
+// profiles/r03_hbm_traffic.csv had the grouped launch reading 1.0 GB for 0.41 GB of operands, at 6 TB/s -- bandwidth-bound on its own re-reads).
+#define TN_MAP_MAX 512
+struct TnJobs { int n, wg_total, tiles_total, mapped; int tile0[TN_MAX_JOBS + 1]; TnJob j[TN_MAX_JOBS]; unsigned short map[TN_MAP_MAX]; };
 
 template <bool PP>
 __global__ __launch_bounds__(512, 1) void gemm_tn256_group_k(const TnJobs jobs, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int ji = 0;
+    int ji = 0, local;
+    if (jobs.mapped) {
+        const unsigned m = jobs.map[blockIdx.x];
+        ji = (int)(m >> 12);
+        local = (int)(m & 0xfff);
+    } else {
 #pragma unroll
-    for (int i = 1; i < TN_MAX_JOBS; ++i) ji += (i < jobs.n && (int)blockIdx.x >= jobs.j[i].wg0) ? 1 : 0;      // products sit in wg0 order
+        for (int i = 1; i < TN_MAX_JOBS; ++i) ji += (i < jobs.n && (int)blockIdx.x >= jobs.j[i].wg0) ? 1 : 0;      // products sit in wg0 order
+        local = blockIdx.x - jobs.j[ji].wg0;
+    }
     const TnJob& J = jobs.j[ji];
-    tn256_body<PP>(smem, blockIdx.x - J.wg0, J.dY, J.ldy, J.X, J.ldx, J.M, J.N, J.K, J.tiles_k, J.nsplit, J.per,
+    tn256_body<PP>(smem, local, J.dY, J.ldy, J.X, J.ldx, J.M, J.N, J.K, J.tiles_k, J.nsplit, J.per,
                    slabs + (size_t)J.slab0 * T_SLAB_FLOATS, J.dW, J.ldw, J.dbias, true);
 }
 
@@ -405,6 +417,54 @@ static bool tn256_group_shape_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, i
 }
 extern "C" int mvuld_gemm_tn_wgrad_group_ok(int M, int N, int K, int64_t ldy, int64_t ldx) { return tn256_group_shape_ok(M, N, K, ldy, ldx) ? 1 : 0; }
 
+// XCD-aware deal of the launch-order blocks (see TnJobs::map): (product, split) groups, largest first, each onto the XCD with the least
+// room that still takes it whole (else spread over the emptiest ones).  MVULD_TN256_XCD_MAP=0: launch order = product order.
+static void tn256_group_map(TnJobs& T) {
+    static const bool on = [] { const char* e = getenv("MVULD_TN256_XCD_MAP"); return !e || atoi(e) != 0; }();
+    T.mapped = 0;
+    if (!on || T.wg_total > TN_MAP_MAX) return;
+    for (int i = 0; i < T.n; ++i)
+        if ((int64_t)cdiv(T.j[i].N, 256) * T.j[i].tiles_k * T.j[i].nsplit > 4096) return;
+    int freec[8], nexti[8];
+    for (int x = 0; x < 8; ++x) { freec[x] = (T.wg_total - x + 7) / 8; nexti[x] = 0; }
+    struct Grp { int job, ks, size; };
+    Grp g[TN_MAX_JOBS * 64];
+    int ng = 0;
+    for (int i = 0; i < T.n; ++i) {
+        const int tiles = (int)cdiv(T.j[i].N, 256) * T.j[i].tiles_k;
+        for (int ks = 0; ks < T.j[i].nsplit; ++ks) {
+            if (ng == TN_MAX_JOBS * 64) return;
+            g[ng++] = Grp{i, ks, tiles};
+        }
+    }
+    for (int a = 1; a < ng; ++a) {          // insertion sort, largest first
+        const Grp v = g[a];
+        int b = a - 1;
+        while (b >= 0 && g[b].size < v.size) { g[b + 1] = g[b]; --b; }
+        g[b + 1] = v;
+    }
+    for (int a = 0; a < ng; ++a) {
+        int tile = 0;
+        while (tile < g[a].size) {
+            const int need = g[a].size - tile;
+            int best = -1;
+            for (int x = 0; x < 8; ++x)      // smallest room that takes the rest whole
+                if (freec[x] >= need && (best < 0 || freec[x] < freec[best])) best = x;
+            if (best < 0)
+                for (int x = 0; x < 8; ++x)  // else the emptiest XCD
+                    if (freec[x] > 0 && (best < 0 || freec[x] > freec[best])) best = x;
+            if (best < 0) return;           // (cannot happen: the slots add up to wg_total)
+            const int take = freec[best] < need ? freec[best] : need;
+            for (int k = 0; k < take; ++k, ++tile) {
+                const int slot = best + 8 * nexti[best]++;
+                T.map[slot] = (unsigned short)((g[a].job << 12) | (tile * T.j[g[a].job].nsplit + g[a].ks));
+            }
+            freec[best] -= take;
+        }
+    }
+    T.mapped = 1;
+}
+
 static int tn256_group_plan(const int64_t* desc, int njobs, TnJobs& T) {
     if (njobs < 1 || njobs > TN_MAX_JOBS) return -1;
     int64_t steps = 0;
@@ -434,10 +494,11 @@ static int tn256_group_plan(const int64_t* desc, int njobs, TnJobs& T) {
             wg += tiles * J.nsplit; slab += tiles * J.nsplit; tile += tiles;
         }
         T.tile0[njobs] = tile;
-        T.n = njobs; T.wg_total = wg; T.tiles_total = tile; T.pad = 0;
-        if (wg <= cus || target >= steps) return 0;
+        T.n = njobs; T.wg_total = wg; T.tiles_total = tile; T.mapped = 0;
+        if (wg <= cus || target >= steps) { tn256_group_map(T); return 0; }
         target += (target + 15) / 16;                    // a few workgroups over one round: longer splits
     }
+    tn256_group_map(T);
     return 0;
 }
 // The workspace has the layout of mvuld_gemm_tn_wgrad's: its first TN_GROUP_WS_HEAD bytes are the ticket block of the 128 x 128 kernel's

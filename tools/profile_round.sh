@@ -10,7 +10,7 @@ cd /tmp
 export TMPDIR=/tmp
 O=$R/gpurun_out/prof
 mkdir -p $O
-B="$R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-varlen --no-infer"
+B="$R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-varlen --no-infer --no-fp8"
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
     rm -rf $O/kt $O/kt2 $O/fetch $O/write
     MVULD_CONCURRENT=0 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt -- python3 $B > $O/kt.log 2>&1
