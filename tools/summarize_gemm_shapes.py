@@ -57,8 +57,12 @@ def main():
                 rd = round(sum(t.get("FETCH_SIZE", 0.0) for t in ts) / len(ts) * 2 * 1024 / 1e6, 1)     # KiB, x2 gfx950 correction
                 wr = round(sum(t.get("WRITE_SIZE", 0.0) for t in ts) / len(ts) * 1024 / 1e6, 1)
             M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
-            alg = 2.0 * (M * K + N * K + M * N + (M * N if r["epilogue"] in ("gelu", "dgelu", "addaux") else 0)) if r["kind"] == "nt" \
-                else 2.0 * (M * K + M * N) + 4.0 * N * K
+            if r["kind"] == "tg":          # a block's four weight gradients (fc2, fc1, proj / out, qkv at width K): operands once + fp32 gradients
+                alg = sum(2.0 * (M * k_ + M * n_) + 4.0 * n_ * k_ for n_, k_ in ((K, 4 * K), (4 * K, K), (K, K), (3 * K, K)))
+            elif r["kind"] == "nt":
+                alg = 2.0 * (M * K + N * K + M * N + (M * N if r["epilogue"] in ("gelu", "dgelu", "addaux") else 0))
+            else:
+                alg = 2.0 * (M * K + M * N) + 4.0 * N * K
             w.writerow([r["shape"], r["kind"], M, N, K, r["epilogue"], r["launches_per_step"], r["us"], r["tflops"],
                         round(float(r["tflops"]) / 2500, 3), ds[0]["name"], ds[0]["vgpr"], ds[0]["lds"],
                         round(avg("SQ_VALU_MFMA_BUSY_CYCLES") / (busy * 4) if busy else 0, 3),
