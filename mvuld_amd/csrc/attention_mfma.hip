@@ -716,7 +716,8 @@ __device__ __forceinline__ float dpp_row(float v) {
 // G row tiles (16 queries x 32 key slots) and the q-side operands of a row are fetched once for all G of them.  The table
 // entry of a register is loop invariant between the two switches of a dy, so dS accumulates in registers; a flush folds the
 // 4-register diagonals of a lane row with DPP shifts before the LDS atomics (3x fewer of them).
-template <int HD, int G>
+// KT = 16-slot key sub-tiles per image row: 2 covers windows up to 32 wide, 1 (ws <= 16) drops the all-padding second half.
+template <int HD, int G, int KT>
 __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(AttnGeom g, const bf16* __restrict__ qkv, const bf16* __restrict__ qt,
                                                              const float* __restrict__ table16, const bf16* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
         // per register: key slot x = 16 t + 4 fg + r' (r = 4 t + r'); bit r of xmask = other x region, of pmask = beyond the row
         unsigned xmask = 0, pmask = 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4 * KT; ++r) {
             const int xk = (r >> 2) * 16 + 4 * fg + (r & 3);
             if (g.shift > 0 && am_rid(g, wx * ws + min(xk, ws - 1)) != rxq) xmask |= 1u << r;
             if (xk >= ws) pmask |= 1u << r;
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
         //  exp() to exactly 0 in fp32 against scores bounded by tau + 16.)
         auto load_bias = [&](float* bj, int dyv) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < 4 * KT; ++r) {
                 const int xkc = min((r >> 2) * 16 + 4 * fg + (r & 3), ws - 1);
                 float v = tab[(dyv + ws - 1) * W2 + (xqc - xkc + ws - 1)];
                 v = ((xmask >> r) & 1) ? v - 100.0f * LOG2E : v;
@@ -781,13 +782,13 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
         };
         // dtab[dy][xq - xk] += acc: lane fc, register r' of tile t lands in column fc - r' + cb(t); the four registers of a
         // diagonal sit in lanes fc..fc+3 of the row, so shl-folds give columns m = fc (16 lanes) and shr-folds m = fc - 3 < 0.
-        auto flush = [&](float* aj, int dyv) {
+        auto flush = [&](f32x2_t* aj, int dyv) {
             float* drow = dtab + (dyv + ws - 1) * W2;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < KT; ++t) {
                 float a[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = (qv && !((pmask >> (4 * t + r)) & 1)) ? aj[4 * t + r] : 0.f;
+                for (int r = 0; r < 4; ++r) a[r] = (qv && !((pmask >> (4 * t + r)) & 1)) ? aj[2 * t + (r >> 1)][r & 1] : 0.f;
                 const float sm = a[0] + dpp_row<0x101>(a[1]) + dpp_row<0x102>(a[2]) + dpp_row<0x103>(a[3]);
                 const float sn = a[3] + dpp_row<0x111>(a[2]) + dpp_row<0x112>(a[1]);
                 const int cb = qp * qw - 16 * t - 4 * fg + ws - 1;
@@ -796,14 +797,15 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
                 if (fc < 3 && cn >= 0 && cn < W2 && sn != 0.f) atomicAdd(drow + cn, sn);
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) aj[r] = 0.f;
+            for (int r = 0; r < 2 * KT; ++r) aj[r] = f32x2_t{0.f, 0.f};
         };
-        float acc[G][8], bias[G][8];
+        f32x2_t acc[G][2 * KT];                        // register r of tile t = acc[.][2 t + (r >> 1)][r & 1]
+        float bias[G][4 * KT];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int dyj = grp * G + j;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[j][r] = 0.f;
+            for (int r = 0; r < 2 * KT; ++r) acc[j][r] = f32x2_t{0.f, 0.f};
             load_bias(bias[j], dyj == 0 ? 0 : min(dyj, ws - 1) - ws);
         }
         const int ka0 = min(fc, ws - 1), ka1 = min(16 + fc, ws - 1);      // A rows: key slot (t, fc) of image row yk
@@ -844,8 +846,8 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
                 const int dyc = min(grp * G + j, ws - 1);
                 const int yk = yq - dyc + (yq < dyc ? ws : 0);
                 const int ko = yk * ws * KLD;                               // scalar
-                fk0[slot] = *(const bf16x8_t*)(Ks + ko + kb0); fk1[slot] = *(const bf16x8_t*)(Ks + ko + kb1);
-                fv0[slot] = *(const bf16x8_t*)(Vs + ko + kb0); fv1[slot] = *(const bf16x8_t*)(Vs + ko + kb1);
+                fk0[slot] = *(const bf16x8_t*)(Ks + ko + kb0); fv0[slot] = *(const bf16x8_t*)(Vs + ko + kb0);
+                if constexpr (KT == 2) { fk1[slot] = *(const bf16x8_t*)(Ks + ko + kb1); fv1[slot] = *(const bf16x8_t*)(Vs + ko + kb1); }
             };
 #if AM_X == 4
             if (yq == 0) { frags(0, 0); frags(1, 1); }
@@ -860,18 +862,23 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
                 const int dyc = min(grp * G + j, ws - 1);
                 const int yk = yq - dyc + (yq < dyc ? ws : 0);
                 const bool ydiff = g.shift > 0 && am_rid(g, wy * ws + yk) != rq;
-                const f32x4_t b0 = {bias[j][0], bias[j][1], bias[j][2], bias[j][3]};
-                const f32x4_t b1 = {bias[j][4], bias[j][5], bias[j][6], bias[j][7]};
-                const f32x4_t s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0[j & 1], cur.q.v, b0, 0, 0, 0);
-                const f32x4_t s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1[j & 1], cur.q.v, b1, 0, 0, 0);
-                const f32x4_t p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[j & 1], cur.d.v, nD, 0, 0, 0);
-                const f32x4_t p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[j & 1], cur.d.v, nD, 0, 0, 0);
                 const float c2 = (ydiff ? -100.0f * LOG2E : 0.f) - L2;
+                // register PAIRS of the MFMA results, spelled out: left to itself the vectoriser pairs registers of different
+                // results and pays two v_mov per v_pk_fma_f32 to line them up (a quarter of the block's instructions)
+                const f32x2_t c22 = {c2, c2};
+                auto tile = [&](const bf16x8_t& fk, const bf16x8_t& fv, const float* bj, f32x2_t* aj) {
+                    const f32x4_t b = {bj[0], bj[1], bj[2], bj[3]};
+                    const f32x4_t sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, cur.q.v, b, 0, 0, 0);
+                    const f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, cur.d.v, nD, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[j][r] = fmaf(__builtin_amdgcn_exp2f(s0[r] + c2), p0[r], acc[j][r]);
-                    acc[j][4 + r] = fmaf(__builtin_amdgcn_exp2f(s1[r] + c2), p1[r], acc[j][4 + r]);
-                }
+                    for (int hp = 0; hp < 2; ++hp) {
+                        const f32x2_t x = f32x2_t{sc[2 * hp], sc[2 * hp + 1]} + c22;
+                        const f32x2_t e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        aj[hp] = __builtin_elementwise_fma(e, f32x2_t{dp[2 * hp], dp[2 * hp + 1]}, aj[hp]);
+                    }
+                };
+                tile(fk0[j & 1], fv0[j & 1], bias[j], acc[j]);
+                if constexpr (KT == 2) tile(fk1[j & 1], fv1[j & 1], bias[j] + 4, acc[j] + 2);
             }
             // first use of the prefetched row pinned behind the tiles (keeps its vmcnt wait out of the MFMA block)
             asm volatile("" : "+v"(nxt.q.v), "+v"(nxt.d.v), "+v"(nxt.L2), "+v"(nxt.D));
@@ -1627,15 +1634,19 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         int sp = 1;
         while ((int64_t)B * nW * H * sp < 256 && sp * 2 <= items) sp *= 2;
         float* part = (ws_part && ws_part_bytes >= (int64_t)B * nW * H * sp * T2 * 4) ? ws_part : nullptr;
-        if (DG == 4) {
-            if (am_set_lds(attn_bwd_dbias_mfma_k<32, 4>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-            hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, 4>), dim3(B * nW * H * sp), dim3(512), bytes, stream, g, (const bf16*)qkv,
-                               (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
-        } else {
-            if (am_set_lds(attn_bwd_dbias_mfma_k<32, 2>, bytes, "attn_bwd_dbias_mfma_k")) return 1;
-            hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, 2>), dim3(B * nW * H * sp), dim3(1024), bytes, stream, g, (const bf16*)qkv,
-                               (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, part, Npad, sp);
-        }
+        // waves per workgroup = work items per workgroup (ws = 14: 4 items; 8 waves would leave half of them idle and the
+        // small tile footprint lets several workgroups share a CU instead)
+        const int per_wg = (items + sp - 1) / sp;
+#define AM_DBIAS(GV, KTV, MAXW)                                                                                          \
+    do {                                                                                                                 \
+        if (am_set_lds(attn_bwd_dbias_mfma_k<32, GV, KTV>, bytes, "attn_bwd_dbias_mfma_k")) return 1;                    \
+        hipLaunchKernelGGL((attn_bwd_dbias_mfma_k<32, GV, KTV>), dim3(B * nW * H * sp), dim3(64 * max(1, min(MAXW, per_wg))), bytes, \
+                           stream, g, (const bf16*)qkv, (const bf16*)ws_qt, table16, (const bf16*)dout, lse, ws_delta, dtable16, \
+                           part, Npad, sp);                                                                              \
+    } while (0)
+        if (DG == 4) { if (ws <= 16) AM_DBIAS(4, 1, 8); else AM_DBIAS(4, 2, 8); }
+        else { if (ws <= 16) AM_DBIAS(2, 1, 16); else AM_DBIAS(2, 2, 16); }
+#undef AM_DBIAS
         if (part)
             hipLaunchKernelGGL(attn_dbias_reduce_k, dim3(cdiv(T2, 256), H, max(1, min(16, B * nW * sp / 8))), dim3(256), 0, stream, part, dtable16, T2, H,
                                B * nW, sp);
