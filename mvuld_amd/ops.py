@@ -38,6 +38,10 @@ def on_backward_done(tag, fn, key="default"):
 
 
 def fire_backward_done(tag):
+    # a weight gradient still deferred in an open wgrad_group (the firing block's own, when its last product has no bias output to
+    # close the group) must be in flight before anything that reads the gradients (the data-parallel exchange) is launched
+    if _WGRAD_PENDING[0]:
+        wgrad_group_flush()
     cbs = list(_BACKWARD_DONE.get(tag, {}).values())
     if (cbs or tag == "swin") and tag.startswith("swin"):
         join_wgrad_stream()               # the image encoder's weight gradients run on their own stream: finish them first

@@ -93,6 +93,35 @@ def test_swin_gradients_vs_oracle(gpu, dtype):
     assert worst[0][0] < lim, worst[:6]
 
 
+def test_backward_done_hook_sees_the_deferred_weight_gradients(gpu):
+    """The data-parallel exchange is launched from the backward-done hook of a stage's first block (distributed.py); with
+    qkv_bias=False that block's last weight gradient has no bias output to close its wgrad_group, so the hook must flush the
+    group itself: a stream-ordered snapshot taken inside the hook already holds the stage's final gradients."""
+    from mvuld_amd import ops, hip
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    m = SwinTransformerV2(num_classes=2, drop_path_rate=0.0, act_dtype=torch.bfloat16, img_size=112, embed_dim=256, depths=[2],
+                          num_heads=[8], window_size=14, qkv_bias=False, pretrained_window_sizes=[0])
+    load_synth_into(m)
+    m = m.to(gpu).train()
+    qkv = m.layers[0].blocks[0].attn.qkv.weight
+    M = 2 * 28 * 28
+    assert ops.USE_WGRAD_GROUPS[0] and hip.LIB.fn("mvuld_gemm_tn_wgrad_group_ok")(M, 768, 256, 768, 256)      # the deferred path is the one under test
+    snap = {}
+
+    def hook():
+        snap["qkv"] = ops.grad_of(qkv).clone()
+
+    ops.on_backward_done("swin.layers.0", hook, key="test")
+    try:
+        f = m.forward_features(_images(2, 112).to(gpu))
+        (f.float() * synth.tensor("swin/hookw", tuple(f.shape)).to(gpu)).sum().backward()
+    finally:
+        ops.on_backward_done("swin.layers.0", None, key="test")
+    torch.cuda.synchronize()
+    assert "qkv" in snap and float(qkv.grad.abs().max()) > 0
+    assert torch.equal(snap["qkv"], qkv.grad)
+
+
 ROB_TINY = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
                 max_position_embeddings=130)
 

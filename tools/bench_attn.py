@@ -9,6 +9,8 @@ B = int(os.environ.get("B", 32))
 cases = [("swin s0", 0, 4, 32, 112, 28, 14), ("swin s0 noshift", 0, 4, 32, 112, 28, 0), ("swin s1", 0, 8, 32, 56, 28, 14),
          ("swin s2", 0, 16, 32, 28, 28, 0), ("swin s3", 0, 32, 32, 14, 14, 0), ("roberta", 1, 12, 64, 0, 0, 0),
          ("roberta packed", 2, 12, 64, 0, 0, 0), ("roberta packed drop", 2, 12, 64, 0, 0, 0)]
+if os.environ.get("GEOM"):            # extra window sizes (wave balance: a window of N tokens is N/16 tiles on 16 waves): GEOM=24,32
+    cases += [(f"swin w{w}", 0, 16, 32, w, w, 0) for w in map(int, os.environ["GEOM"].split(","))]
 which = sys.argv[1:] or ["auto"]
 only = os.environ.get("CASES")
 for name, mode, H, hd, res, ws, shift in cases:
