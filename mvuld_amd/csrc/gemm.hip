@@ -1040,12 +1040,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_mfma_bf16(const bf16* __restri
         if (tid == 0) *flag = __hip_atomic_fetch_add(tickets + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != (unsigned)(nsplit - 1)) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(tickets + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
-        }
-        __syncthreads();
+        // every wave takes the agent-scope acquire itself (buffer_inv): its slab loads below must not be served from lines its own
+        // XCD's L2 cached before the other splits' write-through stores landed
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) __hip_atomic_store(tickets + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
         for (int sidx = 0; sidx < nsplit; ++sidx) {
             if (sidx == ks) continue;
             const float* other = slabs + ((size_t)tl * nsplit + sidx) * (128 * 128);
