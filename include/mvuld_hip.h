@@ -29,7 +29,8 @@ extern "C" {
 typedef struct ihipStream_t* mvuld_stream_t;
 
 enum { MVULD_F32 = 0, MVULD_BF16 = 1 };
-enum { MVULD_EPI_NONE = 0, MVULD_EPI_BIAS = 1, MVULD_EPI_GELU = 2, MVULD_EPI_ELU = 3, MVULD_EPI_MUL_DGELU = 4, MVULD_EPI_MUL_DELU = 5, MVULD_EPI_ADD_AUX = 6 };
+enum { MVULD_EPI_NONE = 0, MVULD_EPI_BIAS = 1, MVULD_EPI_GELU = 2, MVULD_EPI_ELU = 3, MVULD_EPI_MUL_DGELU = 4, MVULD_EPI_MUL_DELU = 5, MVULD_EPI_ADD_AUX = 6,
+       MVULD_EPI_GELU_DG = 7, MVULD_EPI_MUL_AUX = 8 };
 enum { MVULD_OUT_STORE = 0, MVULD_OUT_ACCUM = 1, MVULD_OUT_ATOMIC = 2 };
 
 int mvuld_version(void);
@@ -41,7 +42,10 @@ const char* mvuld_last_error(void);
  *   HF RobertaModel dense layers (unixcoder.py:36); GATConv.fc, GraphModel.py:153-209 Linear layers;
  *   Rs_GCN.py:57-70 (g/theta/phi/W convs, theta^T.phi, R.g).
  * epilogue GELU writes the pre-activation to `aux` (if non-null); MUL_DGELU / MUL_DELU multiply by the
- * activation derivative taken from `aux` (pre-activation / ELU output); ADD_AUX adds `aux` (residual-gradient join).  out_mode ATOMIC (fp32 C only)
+ * activation derivative taken from `aux` (pre-activation / ELU output); ADD_AUX adds `aux` (residual-gradient join).
+ * GELU_DG / MUL_AUX are the FFN's training pair: GELU_DG is GELU whose `aux` receives gelu'(pre-activation) instead (same erf and
+ * exponential: two more instructions per element), MUL_AUX multiplies by `aux` -- the backward product of Mlp.fc2 / RobertaOutput.dense
+ * then has a one-instruction epilogue instead of recomputing erf + exp (swin_transformer_v2.py:27-30, nn.GELU backward).  out_mode ATOMIC (fp32 C only)
  * with splitk > 1 is the weight-gradient form  dW += dY^T . X . */
 int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                   void* C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
@@ -59,7 +63,7 @@ int mvuld_set_gemm_256_min_k(int min_k);
  *   n % 8 == 0; `partials` = 1024 floats of scratch.
  * mvuld_gemm_nt_fp8: C[M,N] (bf16) = epi(scale_a[0] * scale_b[0] * A8[M,K] . B8[N,K]^T + bias) on v_mfma_f32_16x16x32_fp8_fp8 with fp32
  *   accumulation (the persistent 256 x 256 kernel; K % 64 == 0, K >= 256, N % 8 == 0, lda / ldb multiples of 16); epilogue NONE / BIAS /
- *   GELU (+ pre-activation to `aux`).  With the GELU epilogue the activation can leave as e4m3 for the next product without a pass of
+ *   GELU (+ pre-activation to `aux`) / GELU_DG (+ gelu' to `aux`).  With a GELU epilogue the activation can leave as e4m3 for the next product without a pass of
  *   its own: q_out[M,N] (row stride ldq bytes) = e4m3(bf16(gelu) / q_state[0]); max|gelu| is folded into q_state[1] (atomic max on the
  *   float's bits) for the NEXT step's scale ("delayed scaling": mvuld_fp8_roll_scales); C may then be null (inference: fp8 only).
  * mvuld_layernorm_fwd_q8: mvuld_layernorm_fwd that also emits y as e4m3 under q_state[0] and folds max|y| into q_state[1].

@@ -28,6 +28,11 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, TO* C, TO* aux
             if (aux) stf(aux + ai, v);
             v = gelu_erf(v);
             break;
+        case EPI_GELU_DG:
+            if (aux) stf(aux + ai, dgelu_erf(v));
+            v = gelu_erf(v);
+            break;
+        case EPI_MUL_AUX: v *= ldf(aux + ai); break;
         case EPI_ELU: v = elu1(v); break;
         case EPI_MUL_DGELU: v *= dgelu_erf(ldf(aux + ai)); break;
         case EPI_MUL_DELU: { const float y = ldf(aux + ai); v *= (y > 0.f ? 1.0f : y + 1.0f); } break;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
         float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         if (vec_ok) {
             float ax[8];
-            if (g.epi >= EPI_MUL_DGELU) {
+            if (epi_reads_aux(g.epi)) {
                 const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
                 if constexpr (sizeof(TO) == 4) {
                     const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
@@ -309,6 +314,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
                 pre[e] = x;
                 switch (g.epi) {
                     case EPI_GELU: x = gelu_t<TO>(x); break;
+                    case EPI_GELU_DG: gelu_dgelu_t<TO>(x, x, pre[e]); break;      // aux <- gelu'(pre-activation)
+                    case EPI_MUL_AUX: x *= ax[e]; break;
                     case EPI_ELU: x = elu1(x); break;
                     case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                     case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
             if constexpr (sizeof(TO) == 4) {
                 *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                if (g.epi == EPI_GELU && aux) {
+                if (epi_writes_aux(g.epi) && aux) {
                     float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
                     *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
                     *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
                 *(bf16x8*)cp = o;
-                if (g.epi == EPI_GELU && aux) {
+                if (epi_writes_aux(g.epi) && aux) {
                     bf16x8 q;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int 
             float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
             if (vec_ok) {
                 float ax[8];
-                if (g.epi >= EPI_MUL_DGELU) {
+                if (epi_reads_aux(g.epi)) {
                     const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
                     if constexpr (sizeof(TO) == 4) {
                         const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
@@ -503,6 +510,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int 
                     pre[e] = x;
                     switch (g.epi) {
                         case EPI_GELU: x = gelu_t<TO>(x); break;
+                        case EPI_GELU_DG: gelu_dgelu_t<TO>(x, x, pre[e]); break;      // aux <- gelu'(pre-activation)
+                        case EPI_MUL_AUX: x *= ax[e]; break;
                         case EPI_ELU: x = elu1(x); break;
                         case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int 
                 if constexpr (sizeof(TO) == 4) {
                     *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
                         *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
                         *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
                     *(bf16x8*)cp = o;
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         bf16x8 q;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
             float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
             if (vec_ok) {
                 float ax[8];
-                if (g.epi >= EPI_MUL_DGELU) {
+                if (epi_reads_aux(g.epi)) {
                     const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
                     if constexpr (sizeof(TO) == 4) {
                         const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
@@ -684,6 +693,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
                     pre[e] = x;
                     switch (g.epi) {
                         case EPI_GELU: x = gelu_t<TO>(x); break;
+                        case EPI_GELU_DG: gelu_dgelu_t<TO>(x, x, pre[e]); break;      // aux <- gelu'(pre-activation)
+                        case EPI_MUL_AUX: x *= ax[e]; break;
                         case EPI_ELU: x = elu1(x); break;
                         case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
                 if constexpr (sizeof(TO) == 4) {
                     *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
                         *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
                         *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_mfma_bf16_ring128(GemmArgs g, 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
                     *(bf16x8*)cp = o;
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         bf16x8 q;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
             float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
             if (vec_ok) {
                 float ax[8];
-                if (g.epi >= EPI_MUL_DGELU) {
+                if (epi_reads_aux(g.epi)) {
                     const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
                     if constexpr (sizeof(TO) == 4) {
                         const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
@@ -865,6 +876,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
                     pre[e] = x;
                     switch (g.epi) {
                         case EPI_GELU: x = gelu_t<TO>(x); break;
+                        case EPI_GELU_DG: gelu_dgelu_t<TO>(x, x, pre[e]); break;      // aux <- gelu'(pre-activation)
+                        case EPI_MUL_AUX: x *= ax[e]; break;
                         case EPI_ELU: x = elu1(x); break;
                         case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
                         case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
@@ -878,7 +891,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
                 if constexpr (sizeof(TO) == 4) {
                     *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
                         *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
                         *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
@@ -888,7 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_bf16_ring256x128(GemmArgs
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
                     *(bf16x8*)cp = o;
-                    if (g.epi == EPI_GELU && aux) {
+                    if (epi_writes_aux(g.epi) && aux) {
                         bf16x8 q;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
@@ -1132,8 +1145,8 @@ extern "C" int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, in
                                  const float* bias, int epilogue, void* aux, int64_t ldaux, const float* scale_a, const float* scale_b,
                                  void* q_out, int64_t ldq, float* q_state, hipStream_t stream) {
     MV_CHECK_ARG(A8 && B8 && (C || q_out) && M > 0 && N > 0 && K > 0, "gemm_nt_fp8: bad args");
-    MV_CHECK_ARG(!q_out || (q_state && epilogue == EPI_GELU), "gemm_nt_fp8: the e4m3 side output belongs to the GELU epilogue and needs its {scale, amax} pair");
-    MV_CHECK_ARG(epilogue == EPI_NONE || epilogue == EPI_BIAS || epilogue == EPI_GELU, "gemm_nt_fp8: epilogue %d (NONE / BIAS / GELU only)", epilogue);
+    MV_CHECK_ARG(!q_out || (q_state && (epilogue == EPI_GELU || epilogue == EPI_GELU_DG)), "gemm_nt_fp8: the e4m3 side output belongs to the GELU epilogues and needs its {scale, amax} pair");
+    MV_CHECK_ARG(epilogue == EPI_NONE || epilogue == EPI_BIAS || epilogue == EPI_GELU || epilogue == EPI_GELU_DG, "gemm_nt_fp8: epilogue %d (NONE / BIAS / GELU / GELU_DG only)", epilogue);
     GemmArgs g;
     g.A = A8; g.B = B8; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = g.sB = g.sC = 0;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.splitk = 1; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.sAux = 0;
@@ -1162,8 +1175,8 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
                              hipStream_t stream) {
     MV_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_nt: empty problem M=%d N=%d K=%d batch=%d", M, N, K, batch);
     MV_CHECK_ARG(A && B && C, "gemm_nt: null operand");
-    MV_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_ADD_AUX, "gemm_nt: bad epilogue %d", epilogue);
-    MV_CHECK_ARG(!((epilogue >= EPI_MUL_DGELU) && !aux), "gemm_nt: epilogue %d needs aux", epilogue);
+    MV_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_MUL_AUX, "gemm_nt: bad epilogue %d", epilogue);
+    MV_CHECK_ARG(!(epi_reads_aux(epilogue) && !aux), "gemm_nt: epilogue %d needs aux", epilogue);
     MV_CHECK_ARG(out_mode >= OUT_STORE && out_mode <= OUT_ATOMIC, "gemm_nt: bad out_mode %d", out_mode);
     MV_CHECK_ARG(!(out_mode == OUT_ATOMIC && dtype_out != MVULD_F32), "gemm_nt: atomic output must be f32");
     MV_CHECK_ARG(!(out_mode == OUT_ATOMIC && epilogue > EPI_BIAS), "gemm_nt: atomic output with nonlinear epilogue");

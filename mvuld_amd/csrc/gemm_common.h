@@ -2,7 +2,13 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6 };
+// EPI_GELU_DG / EPI_MUL_AUX (round 3): the training pair of the FFN.  The forward product writes gelu'(pre-activation) to aux instead of
+// the pre-activation itself (same bytes; the erf and the exponential are the ones GELU needs anyway: + 2 instructions per element), and
+// the data-gradient product of the second Linear multiplies by it -- a one-instruction epilogue where EPI_MUL_DGELU recomputes erf + exp
+// (17 issue slots per element: a quarter of a K = 512 tile's time, section 9b item 1b of DESIGN.md).
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_GELU = 2, EPI_ELU = 3, EPI_MUL_DGELU = 4, EPI_MUL_DELU = 5, EPI_ADD_AUX = 6, EPI_GELU_DG = 7, EPI_MUL_AUX = 8 };
+__host__ __device__ __forceinline__ constexpr bool epi_reads_aux(int e) { return e >= EPI_MUL_DGELU && e != EPI_GELU_DG; }
+__host__ __device__ __forceinline__ constexpr bool epi_writes_aux(int e) { return e == EPI_GELU || e == EPI_GELU_DG; }
 enum { OUT_STORE = 0, OUT_ACCUM = 1, OUT_ATOMIC = 2 };
 
 struct GemmArgs {
@@ -39,6 +45,24 @@ __device__ __forceinline__ float dgelu_fast(float x) {
     const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
     const float pdf = 0.39894228040143268f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
     return fmaf(x, pdf, cdf);
+}
+
+// gelu(x) and gelu'(x) from one erf / one exponential; gl is gelu_fast(x) bit for bit
+__device__ __forceinline__ void gelu_dgelu_fast(float x, float& gl, float& dg) {
+    const float u = x * 0.70710678118654752f, ax = fabsf(u);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);      // exp(-x^2 / 2)
+    const float erf = copysignf(fmaf(-p * t, e, 1.0f), u);
+    gl = 0.5f * x * (1.0f + erf);
+    dg = fmaf(x, 0.39894228040143268f * e, 0.5f * (1.0f + erf));
+}
+template <typename TO> __device__ __forceinline__ void gelu_dgelu_t(float x, float& gl, float& dg) {
+    if constexpr (sizeof(TO) == 2) gelu_dgelu_fast(x, gl, dg);
+    else { gl = gelu_erf(x); dg = dgelu_erf(x); }
 }
 
 template <typename TO> __device__ __forceinline__ float gelu_t(float x) {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     // stores one epilogue leaves in flight (known exactly only for a wave whose sub-tile is interior: every store executes)
     constexpr int ST1 = 2 * NI, ST2 = 4 * NI, ST3 = 6 * NI;
     int pend = 0;
-    const bool QE = FP8 && EPI == EPI_GELU && g.q_out != nullptr;      // workgroup-uniform
+    const bool QE = FP8 && (EPI == EPI_GELU || EPI == EPI_GELU_DG) && g.q_out != nullptr;      // workgroup-uniform
     float amax_l = 0.f;
     int cs = 0;                                          // compute step, counted across tiles (ring stage = cs & 3)
     // Step xcs (k-step xkt of its tile) has landed once at most the operations issued after it are still in flight: normally the two
@@ -422,7 +422,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         }
         // aux operands (dGELU pre-activation / residual-gradient join) as the same 16-byte row segments the stores use, fetched one
         // fragment row ahead of their use: a load issued right before its use would wait for every store in front of it
-        constexpr bool AUX_IN = EPI >= EPI_MUL_DGELU;
+        constexpr bool AUX_IN = epi_reads_aux(EPI);
+        constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_DG;
         uint4 z[NI][2];
         auto load_aux = [&](int i) {
             const int row = mw + i * 16 + fr;
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                             float t = alpha * acc[i][j0 + h][r] + b4[j0 + h][r];
                             if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
                             else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
+                            else if (EPI == EPI_MUL_AUX) t *= x[h][r];
                             else if (EPI == EPI_ADD_AUX) t += x[h][r];
                             acc[i][j0 + h][r] = t;
                         }
@@ -499,7 +501,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                         if (TWO_PASS) {}
                         else if (P256_X & 2) { if (EPI == EPI_MUL_DGELU) t *= x[h][r]; }
                         else if (EPI == EPI_GELU) t = gelu_fast(t);
+                        else if (EPI == EPI_GELU_DG) gelu_dgelu_fast(t, t, pre[h][r]);      // aux <- gelu'(pre-activation)
                         else if (EPI == EPI_MUL_DGELU) t *= dgelu_fast(x[h][r]);
+                        else if (EPI == EPI_MUL_AUX) t *= x[h][r];
                         else if (EPI == EPI_ADD_AUX) t += x[h][r];
                         v[h][r] = t;
                     }
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                     if (ok) p_st16(C + (int64_t)srow * g.ldc + col, s0[0], s1[0], s0[1], s1[1]);
                     if (P256_X & 1) asm volatile("" ::"v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]));
                 }
-                if constexpr (FP8 && EPI == EPI_GELU) {
+                if constexpr (FP8 && IS_GELU) {
                     if (QE) {
                         // the bf16-rounded activation, re-quantised for the next product: 4 + 4 columns per lane before the swap
                         unsigned d[2];
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                         if (ok) *(uint2*)((char*)g.q_out + (int64_t)row * g.ldq + col) = make_uint2(t[0], t[1]);
                     }
                 }
-                if (EPI == EPI_GELU && aux) {
+                if (IS_GELU && aux) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][0], pre[0][1]), pk_bf16(pre[1][0], pre[1][1]), false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk_bf16(pre[0][2], pre[0][3]), pk_bf16(pre[1][2], pre[1][3]), false, false);
                     if (ok) p_st16(aux + (int64_t)srow * g.ldaux + col, s0[0], s1[0], s0[1], s1[1]);
@@ -537,9 +541,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             }
         }
         const bool interior = NF || ((mw + WM <= g.M) && (nw + 64 <= g.N));      // wave-uniform: every store above was issued
-        pend = interior ? ST1 * ((C ? 1 : 0) + ((EPI == EPI_GELU && aux) ? 1 : 0) + (QE ? 1 : 0)) : 0;
+        pend = interior ? ST1 * ((C ? 1 : 0) + ((IS_GELU && aux) ? 1 : 0) + (QE ? 1 : 0)) : 0;
     }
-    if constexpr (FP8 && EPI == EPI_GELU) {
+    if constexpr (FP8 && (EPI == EPI_GELU || EPI == EPI_GELU_DG)) {
         if (QE) {
             const float m = wave_max(amax_l);
             if (lane == 0 && m > __uint_as_float(__hip_atomic_load(g.q_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -647,7 +651,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
             }
         }
         constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
-        if constexpr (EPI == EPI_MUL_DGELU || EPI == EPI_ADD_AUX) {
+        if constexpr (epi_reads_aux(EPI)) {
             // unconditional-store epilogue (template parameter NF) wherever every wave's 64 columns are all inside or all outside the
             // matrix and the output does not alias the aux operand: bit-identical, -2..8 % on these products
             if (g.N % 64 == 0 && g.aux != g.C) {
@@ -779,12 +783,13 @@ int mvuld_gemm_nt_p256_fp8(const GemmArgs& g, hipStream_t stream) {
     if (g.lda % 16 != 0 || g.ldb % 16 != 0 || ((((uintptr_t)g.A) | ((uintptr_t)g.B)) & 15) != 0) return -1;
     if (g.aux && (g.ldaux % 8 != 0 || (((uintptr_t)g.aux) & 15) != 0)) return -1;
     if (g.bias && (((uintptr_t)g.bias) & 15) != 0) return -1;
-    if (g.q_out && (g.epi != EPI_GELU || !g.q_scale || !g.q_amax || g.ldq % 8 != 0 || (((uintptr_t)g.q_out) & 7) != 0)) return -1;
+    if (g.q_out && ((g.epi != EPI_GELU && g.epi != EPI_GELU_DG) || !g.q_scale || !g.q_amax || g.ldq % 8 != 0 || (((uintptr_t)g.q_out) & 7) != 0)) return -1;
     if (!g.C && !g.q_out) return -1;
     const int tiles_n = (int)cdiv(g.N, P_BN);
     switch (g.epi) {
         case EPI_NONE: case EPI_BIAS: p256_launch_fp8<EPI_BIAS>(g, tiles_n, stream); break;
         case EPI_GELU: p256_launch_fp8<EPI_GELU>(g, tiles_n, stream); break;
+        case EPI_GELU_DG: p256_launch_fp8<EPI_GELU_DG>(g, tiles_n, stream); break;
         default: return -1;
     }
     return 0;
@@ -833,7 +838,8 @@ int mvuld_gemm_nt_p256_try(const GemmArgs& g, int dtype_out, hipStream_t stream)
     switch (g.epi) {
         case EPI_NONE: case EPI_BIAS: p256_launch_ni<EPI_BIAS>(g, ni, tiles_n, stream); break;
         case EPI_GELU: p256_launch_ni<EPI_GELU>(g, ni, tiles_n, stream); break;
-        case EPI_MUL_DGELU: p256_launch_ni<EPI_MUL_DGELU>(g, ni, tiles_n, stream); break;
+        case EPI_GELU_DG: p256_launch_ni<EPI_GELU_DG>(g, ni, tiles_n, stream); break;
+        case EPI_MUL_AUX: p256_launch_ni<EPI_MUL_AUX>(g, ni, tiles_n, stream); break;      // (EPI_MUL_DGELU: the rings of gemm.hip)
         case EPI_ADD_AUX: p256_launch_ni<EPI_ADD_AUX>(g, ni, tiles_n, stream); break;
         default: return -1;
     }

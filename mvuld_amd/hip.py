@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MVULD_HIP_LIB") or os.path.join(_HERE, "libmvuld_hip.
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mvuld_hip.h")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_GELU, EPI_ELU, EPI_MUL_DGELU, EPI_MUL_DELU, EPI_ADD_AUX = range(7)
+EPI_NONE, EPI_BIAS, EPI_GELU, EPI_ELU, EPI_MUL_DGELU, EPI_MUL_DELU, EPI_ADD_AUX, EPI_GELU_DG, EPI_MUL_AUX = range(9)
 OUT_STORE, OUT_ACCUM, OUT_ATOMIC = range(3)
 
 _CT = {

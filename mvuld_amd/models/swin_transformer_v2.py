@@ -103,11 +103,11 @@ class _SwinBlockFn(torch.autograd.Function):
             # C = 128 / 256 (stages 0 and 1): fc1 + GELU + fc2 in one kernel, hidden on the chip; backward recomputes the pre-activation
             hact, m = ops.mlp_fused_fwd(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, need_h=need_bwd)
         elif fp8:
-            hact, hq = ops.linear_fwd(x1, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre, xq=x1q,
+            hact, hq = ops.linear_fwd(x1, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias.data, epi=ops.gelu_epi(hpre), aux=hpre, xq=x1q,
                                       emit=ops.fp8_site(blk, "h", x.device), need_out=need_bwd)
             m = ops.linear_fwd(hact, blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias.data, xq=hq)
         else:
-            hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=hip.EPI_GELU, aux=hpre)
+            hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=ops.gelu_epi(hpre), aux=hpre)
             m = ops.gemm_nt(hact, ops.weight(blk.mlp.fc2.weight, ad), bias=blk.mlp.fc2.bias.data)
         x2, mean2, rstd2, _, x2q = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1, rowscale=rowscale,
                                                      rows_per_sample=L,
@@ -115,6 +115,7 @@ class _SwinBlockFn(torch.autograd.Function):
         ops.fp8_put(x2, x2q)                # the next block's QKV product takes it
         ctx.save_for_backward(x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale)
         ctx.blk, ctx.geom = blk, geom
+        ctx.dgelu_epi = ops.dgelu_epi(hpre)  # what hpre holds: gelu'(pre-activation) (EPI_GELU_DG -> EPI_MUL_AUX) or the pre-activation itself
         return x2
 
     @staticmethod
@@ -139,7 +140,7 @@ class _SwinBlockFn(torch.autograd.Function):
             dhpre, g1 = ops.mlp_fused_bwd(x1, dm, g, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight)
             ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
         else:
-            dhpre = ops.gemm_nt(dm, ops.weight_t(blk.mlp.fc2.weight, ad), epi=hip.EPI_MUL_DGELU, aux=hpre)
+            dhpre = ops.gemm_nt(dm, ops.weight_t(blk.mlp.fc2.weight, ad), epi=ctx.dgelu_epi, aux=hpre)
             ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
             g1 = ops.gemm_nt(dhpre, ops.weight_t(blk.mlp.fc1.weight, ad), epi=hip.EPI_ADD_AUX, aux=g)
         # ---- attention branch: x1 = x + rs * LN(proj)

@@ -247,11 +247,11 @@ class _LayerFn(torch.autograd.Function):
         it, ot = layer.intermediate, layer.output
         ipre = torch.empty((x.shape[0], cfg.intermediate_size), dtype=ad, device=x.device) if need_bwd else None
         if fp8:
-            iact, iq = ops.linear_fwd(x1, it.dense.weight, bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre, xq=x1q,
+            iact, iq = ops.linear_fwd(x1, it.dense.weight, bias=it.dense.bias.data, epi=ops.gelu_epi(ipre), aux=ipre, xq=x1q,
                                       emit=ops.fp8_site(layer, "h", x.device), need_out=need_bwd)
             o = ops.linear_fwd(iact, ot.dense.weight, bias=ot.dense.bias.data, xq=iq)
         else:
-            iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=hip.EPI_GELU, aux=ipre)
+            iact = ops.gemm_nt(x1, ops.weight(it.dense.weight, ad), bias=it.dense.bias.data, epi=ops.gelu_epi(ipre), aux=ipre)
             o = ops.gemm_nt(iact, ops.weight(ot.dense.weight, ad), bias=ot.dense.bias.data)
         if ph > 0.0 and not fp8:
             x2, mean2, rstd2, s2 = ops.layernorm_dropout_fwd(o, ot.LayerNorm.weight.data, ot.LayerNorm.bias.data, cfg.layer_norm_eps, x1, ph, seeds[2])
@@ -264,6 +264,7 @@ class _LayerFn(torch.autograd.Function):
         ops.fp8_put(x2, x2q)                # the next layer's QKV product takes it
         ctx.save_for_backward(x, valid, qkv, cx, lse, s1, mean1, rstd1, x1, ipre, iact, s2, mean2, rstd2)
         ctx.layer, ctx.geom, ctx.hdrop = layer, geom, (ph, seeds[1], seeds[2])
+        ctx.dgelu_epi = ops.dgelu_epi(ipre)  # what ipre holds: gelu'(pre-activation) (EPI_GELU_DG -> EPI_MUL_AUX) or the pre-activation itself
         return x2
 
     @staticmethod
@@ -281,7 +282,7 @@ class _LayerFn(torch.autograd.Function):
         ds2 = ops.layernorm_bwd(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2)      # d(dropout(o) + x1)
         do = ops.dropout(ds2, ph, seed2)                                                                       # d(o): the residual keeps ds2
         ops.linear_wgrad(do, iact, ot.dense.weight, ot.dense.bias)
-        dipre = ops.gemm_nt(do, ops.weight_t(ot.dense.weight, ad), epi=hip.EPI_MUL_DGELU, aux=ipre)
+        dipre = ops.gemm_nt(do, ops.weight_t(ot.dense.weight, ad), epi=ctx.dgelu_epi, aux=ipre)
         ops.linear_wgrad(dipre, x1, it.dense.weight, it.dense.bias)
         g1 = ops.gemm_nt(dipre, ops.weight_t(it.dense.weight, ad), epi=hip.EPI_ADD_AUX, aux=ds2)
         ds1 = ops.layernorm_bwd(g1, s1, ao.LayerNorm.weight, ao.LayerNorm.bias, mean1, rstd1)

@@ -379,6 +379,21 @@ def linear_fwd(x, w_param, bias=None, epi=hip.EPI_NONE, aux=None, xq=None, emit=
     return (out, None) if emit is not None else out
 
 
+# The FFN's training pair (csrc/gemm_common.h): the forward product leaves gelu'(pre-activation) in the buffer that used to hold the
+# pre-activation, the backward product of the second Linear multiplies by it instead of recomputing erf + exp per element.
+USE_GELU_DG = [os.environ.get("MVULD_GELU_DG", "1") != "0"]
+
+
+def gelu_epi(aux):
+    """Epilogue code of the forward fc1 / intermediate.dense product given its side buffer (None: inference)."""
+    return hip.EPI_GELU_DG if (aux is not None and USE_GELU_DG[0]) else hip.EPI_GELU
+
+
+def dgelu_epi(aux):
+    """... and of the matching backward product: decided in the forward and carried in the autograd context."""
+    return hip.EPI_MUL_AUX if (aux is not None and USE_GELU_DG[0]) else hip.EPI_MUL_DGELU
+
+
 # fused MLP (csrc/mlp_panel.hip): widest block width that takes it -- 0 = never, 128 (default) = Swin stage 0, 256 = stages 0 and 1
 FUSED_MLP_MAX_C = [int(os.environ.get("MVULD_FUSED_MLP", "128"))]
 FUSED_MLP_TRAIN = [os.environ.get("MVULD_FUSED_MLP_TRAIN", "1") != "0"]      # also in training (forward + recomputing backward)

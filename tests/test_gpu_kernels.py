@@ -52,6 +52,13 @@ def test_gemm_nt_bias_epilogues(gpu, dtype, M, N, K):
     assert rel(out, (a @ b.t()) * p.grad) < tol(dtype)
     out = ops.gemm_nt(A, B_, epi=hip.EPI_ADD_AUX, aux=dev(pre, dtype))
     assert rel(out, a @ b.t() + pre) < tol(dtype)
+    # the FFN's training pair: GELU whose side output is gelu'(pre-activation), and the product that multiplies by it
+    out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU_DG, aux=aux)
+    r = ref.clone().requires_grad_(True)
+    F.gelu(r).sum().backward()
+    assert rel(out, F.gelu(ref)) < tol(dtype) and rel(aux, r.grad) < tol(dtype)
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_AUX, aux=dev(pre, dtype))
+    assert rel(out, (a @ b.t()) * pre) < tol(dtype)
     out32 = ops.gemm_nt(A, B_, bias=Bi, out_dtype=torch.float32)
     assert out32.dtype == torch.float32 and rel(out32, ref) < (2e-4 if dtype == torch.float32 else 1e-2)
 
@@ -125,6 +132,12 @@ def _gemm_large_ragged(gpu, K):
     F.gelu(p).sum().backward()
     out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_DGELU, aux=P)
     assert rel(out, ref * p.grad) < 1e-2
+    out = ops.gemm_nt(A, B_, epi=hip.EPI_MUL_AUX, aux=P)
+    assert rel(out, ref * pre.float()) < 1e-2
+    r = (ref + bias).clone().requires_grad_(True)
+    F.gelu(r).sum().backward()
+    out = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU_DG, aux=aux)
+    assert rel(aux, r.grad) < 1e-2 and rel(out, F.gelu(ref + bias)) < 1e-2
 
 
 K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "1"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
@@ -163,7 +176,7 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         repeated launches below."""
         pp(1)
         o1 = ops.gemm_nt(A, B_, **kw)
-        a1 = kw["aux"].clone() if kw.get("epi") == hip.EPI_GELU else None
+        a1 = kw["aux"].clone() if kw.get("epi") in (hip.EPI_GELU, hip.EPI_GELU_DG) else None
         pp(0)
         o0 = ops.gemm_nt(A, B_, **kw)
         pp(1)
@@ -204,8 +217,18 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         assert rel(out, ref + pre.float()) < 1e-2
         p = pre.float().clone().requires_grad_(True)
         F.gelu(p).sum().backward()
-        out = both(epi=hip.EPI_MUL_DGELU, aux=P)
+        out = both(epi=hip.EPI_MUL_DGELU, aux=P)          # (not this kernel's any more: the rings of gemm.hip)
         assert rel(out, ref * p.grad) < 1e-2
+        # the training pair: same activation as EPI_GELU, gelu' as the side output; then the one-multiply backward epilogue
+        act = ops.gemm_nt(A, B_, bias=Bi, epi=hip.EPI_GELU, aux=torch.empty_like(aux))
+        dg = torch.empty_like(aux)
+        out = both(bias=Bi, epi=hip.EPI_GELU_DG, aux=dg)
+        assert torch.equal(out, act)
+        r = (ref + bias).clone().requires_grad_(True)
+        F.gelu(r).sum().backward()
+        assert rel(dg, r.grad) < 1e-2
+        out = both(epi=hip.EPI_MUL_AUX, aux=P)
+        assert rel(out, ref * pre.float()) < 1e-2
     finally:
         hip.LIB.fn("mvuld_set_gemm_p256_mode")(1)
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
@@ -285,6 +308,10 @@ def test_gemm_nt_fp8_vs_dequantised_product(gpu, M, N, K):
     aux = torch.empty((M, N), dtype=torch.bfloat16, device=gpu)
     out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU, aux=aux)
     assert rel(aux, ref + bias) < 4e-3 and rel(out, F.gelu(ref + bias)) < 1e-2
+    dg = torch.empty_like(aux)                           # training form: gelu'(pre-activation) as the side output
+    r = (ref + bias).clone().requires_grad_(True)
+    F.gelu(r).sum().backward()
+    assert torch.equal(ops.gemm_nt_fp8(qa, sa, qb, sb, bias=Bi, epi=hip.EPI_GELU_DG, aux=dg), out) and rel(dg, r.grad) < 4e-3
     # the lockstep schedule of the main loop gives the same bytes as the ping-pong one (default), launch after launch
     # (K % 128 == 0: the default is the 128-byte full-line ring; otherwise the 64-byte ring under the ping-pong schedule)
     pp, k64 = hip.LIB.fn("mvuld_set_gemm_p256_pingpong"), hip.LIB.fn("mvuld_set_gemm_p256_k64")
@@ -426,6 +453,9 @@ def test_fast_erf_gelu_epilogue_accuracy(gpu):
             ones = torch.ones((n, n), dtype=torch.bfloat16, device=gpu)
             out = ops.gemm_nt(ones, eye, epi=hip.EPI_MUL_DGELU, aux=X.to(gpu))     # (1 . I^T) * gelu'(x)
             assert float((out.float().cpu() - p.grad).abs().max()) < 1e-2
+            act = ops.gemm_nt(X.to(gpu), eye, epi=hip.EPI_GELU_DG, aux=aux)          # gelu(x) with gelu'(x) as the side output
+            assert float((act.float().cpu() - ref).abs().max()) <= 2.0 ** -8 * 9.0 + 1e-6
+            assert float((aux.float().cpu() - p.grad).abs().max()) <= 2.0 ** -8 * 1.13 + 1e-6      # bf16 rounding of |gelu'| <= 1.13
         finally:
             hip.LIB.fn("mvuld_set_gemm_p256_mode")(1)
 

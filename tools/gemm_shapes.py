@@ -18,7 +18,10 @@ import torch  # noqa: E402
 from mvuld_amd import hip, ops  # noqa: E402
 
 B = int(os.environ.get("GS_BATCH", 32))
-EPI = {"none": hip.EPI_NONE, "bias": hip.EPI_BIAS, "gelu": hip.EPI_GELU, "dgelu": hip.EPI_MUL_DGELU, "addaux": hip.EPI_ADD_AUX}
+# "gelu" / "dgelu" rows are issued as the step issues them: the training pair EPI_GELU_DG / EPI_MUL_AUX (GS_GELU_DG=0: the round-2 pair)
+_DG = os.environ.get("GS_GELU_DG", "1") != "0"
+EPI = {"none": hip.EPI_NONE, "bias": hip.EPI_BIAS, "gelu": hip.EPI_GELU_DG if _DG else hip.EPI_GELU,
+       "dgelu": hip.EPI_MUL_AUX if _DG else hip.EPI_MUL_DGELU, "addaux": hip.EPI_ADD_AUX}
 
 
 GROUPED = os.environ.get("GS_GROUPED", "1") != "0"      # weight gradients of a block as the step issues them: one grouped launch (kind "tg")
