@@ -169,6 +169,12 @@ int mvuld_layernorm_fwd(const void* x, const void* pre, void* xsum, const float*
 int mvuld_layernorm_fwd_drop(const void* x, const void* pre, void* xsum, const float* gamma, const float* beta, void* y, float* mean,
                              float* rstd, int64_t rows, int C, float eps, float drop_p, uint64_t drop_seed, const uint64_t* seed_offset,
                              mvuld_stream_t stream);
+/* mvuld_layernorm_bwd (no row scale) that also writes dxd = mvuld_dropout(dx, p, seed), bit-identical to the two launches (bf16, C % 8 == 0,
+ * 16-byte aligned): the backward of the same two RoBERTa blocks -- d(dense output) = mask o d(dropout(dense) + input) / (1 - p), while the
+ * residual branch keeps dx.  ws as for mvuld_layernorm_bwd. */
+int mvuld_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, void* dxd,
+                             float* dgamma, float* dbeta, int64_t rows, int C, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed,
+                             const uint64_t* seed_offset, mvuld_stream_t stream);
 /* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta accumulate (+=).  `ws` (optional, fp32,
  * ws_bytes >= 512*C) lends room for per-block column partials summed by a second kernel; without it the column sums
  * are device atomics (slower: ~1.5M contended atomics per launch at C=768). */

@@ -251,12 +251,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_k(const bf16* __restric
     }
 }
 
-template <int CPL>
+// DROP: also writes dxd = dropout(dx, p, seed) -- mvuld_dropout's mask and bits on the bf16-rounded dx -- so that the text encoder's
+// backward hidden dropouts (d(dense output) = mask o d(dropout(dense) + input) / (1 - p)) cost one more store here instead of a pass
+template <int CPL, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_k(const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ rowscale, int rows_per_sample, bf16* __restrict__ dx,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int G, float* __restrict__ ws) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C, int G, float* __restrict__ ws,
+                                                           bf16* __restrict__ dxd = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
+                                                           const uint64_t* __restrict__ drop_off = nullptr) {
     __shared__ float accg[1024], accb[1024];
+    if (DROP && drop_off) drop_seed += drop_off[0] * 0xD1B54A32D192ED03ULL;
+    const float drop_inv = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uint32_t drop_thr = DROP ? (uint32_t)(drop_p * 4294967296.0) : 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane & (G - 1), rg = lane / G, rpw = 64 / G;
     const int nch = C >> 3;
@@ -312,6 +319,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_k(const bf16* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) o.v[e] = (bf16)(rs * (g[i][e] - s1 - xh[i][e] * s2));
             if (rok && chok[i]) *(bf16x8*)(dx + r * C + chc[i] * 8) = o;
+            if (DROP) {
+                bf16x8 od;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool keep = mix32(drop_seed + (uint64_t)(rc * C + chc[i] * 8 + e) * 0x9E3779B97F4A7C15ULL) >= drop_thr;
+                    od.v[e] = (bf16)(keep ? (float)o.v[e] * drop_inv : 0.f);
+                }
+                if (rok && chok[i]) *(bf16x8*)(dxd + r * C + chc[i] * 8) = od;
+            }
         }
     }
     // column partials: fold the row groups of a wave by shuffles, then the waves take turns adding into the LDS accumulators
@@ -494,6 +510,34 @@ extern "C" int mvuld_layernorm_bwd(const void* dy, const void* x, const float* g
         hipLaunchKernelGGL(layernorm_bwd_k<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x,
                            gamma, mean, rstd, rowscale, rows_per_sample, (bf16*)dx, dgamma, dbeta, rows, C);
     MV_LAUNCH_CHECK("layernorm_bwd");
+    return 0;
+}
+
+// mvuld_layernorm_bwd (no row scale) that also emits dxd = mvuld_dropout(dx, p, seed): bf16, C % 8 == 0, 16-byte aligned; bit-identical to
+// the two launches.  The backward of RobertaSelfOutput / RobertaOutput: LayerNorm(dropout(dense(h)) + input).
+extern "C" int mvuld_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, void* dxd,
+                                        float* dgamma, float* dbeta, int64_t rows, int C, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed,
+                                        const uint64_t* seed_offset, hipStream_t stream) {
+    MV_CHECK_ARG(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * LN_MAXPL, "layernorm_bwd_drop: rows=%lld C=%d unsupported", (long long)rows, C);
+    MV_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dxd && drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd_drop: bad args");
+    MV_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dxd | (uintptr_t)gamma) & 15) == 0, "layernorm_bwd_drop: 16-byte aligned tensors only");
+    const int G = ln_group(C), rpw = 64 / G;
+    static const int capv = getenv("MVULD_LN_BWD_GRID") ? atoi(getenv("MVULD_LN_BWD_GRID")) : 1024;
+    int gridv = (int)min((int64_t)capv, cdiv(rows, (int64_t)4 * rpw));
+    float* part = nullptr;
+    if (ws && ws_bytes >= (int64_t)8 * C * 64) {
+        gridv = (int)min((int64_t)gridv, ws_bytes / ((int64_t)8 * C));
+        part = ws;
+    }
+    if (C / 8 <= G)
+        hipLaunchKernelGGL((layernorm_bwd_vec_k<1, true>), dim3(gridv), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd,
+                           (const float*)nullptr, 1, (bf16*)dx, dgamma, dbeta, rows, C, G, part, (bf16*)dxd, drop_p, drop_seed, seed_offset);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_vec_k<2, true>), dim3(gridv), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd,
+                           (const float*)nullptr, 1, (bf16*)dx, dgamma, dbeta, rows, C, G, part, (bf16*)dxd, drop_p, drop_seed, seed_offset);
+    if (part && (dgamma || dbeta))
+        hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3(cdiv(2 * C, 64), 8), dim3(1024), 0, stream, part, gridv, C, dgamma, dbeta);
+    MV_LAUNCH_CHECK("layernorm_bwd_drop");
     return 0;
 }
 

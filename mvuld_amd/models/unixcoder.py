@@ -279,14 +279,13 @@ class _LayerFn(torch.autograd.Function):
         ad = x.dtype
         sa, ao, it, ot = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
         ph, seed1, seed2 = ctx.hdrop
-        ds2 = ops.layernorm_bwd(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2)      # d(dropout(o) + x1)
-        do = ops.dropout(ds2, ph, seed2)                                                                       # d(o): the residual keeps ds2
+        # d(dropout(o) + x1) and d(o) = its dropout: one pass (the residual keeps ds2)
+        ds2, do = ops.layernorm_bwd_dropout(g.contiguous(), s2, ot.LayerNorm.weight, ot.LayerNorm.bias, mean2, rstd2, ph, seed2)
         ops.linear_wgrad(do, iact, ot.dense.weight, ot.dense.bias)
         dipre = ops.gemm_nt(do, ops.weight_t(ot.dense.weight, ad), epi=ctx.dgelu_epi, aux=ipre)
         ops.linear_wgrad(dipre, x1, it.dense.weight, it.dense.bias)
         g1 = ops.gemm_nt(dipre, ops.weight_t(it.dense.weight, ad), epi=hip.EPI_ADD_AUX, aux=ds2)
-        ds1 = ops.layernorm_bwd(g1, s1, ao.LayerNorm.weight, ao.LayerNorm.bias, mean1, rstd1)
-        da = ops.dropout(ds1, ph, seed1)
+        ds1, da = ops.layernorm_bwd_dropout(g1, s1, ao.LayerNorm.weight, ao.LayerNorm.bias, mean1, rstd1, ph, seed1)
         ops.linear_wgrad(da, cx, ao.dense.weight, ao.dense.bias)
         dcx = ops.gemm_nt(da, ops.weight_t(ao.dense.weight, ad))
         dqkv = ops.attn_bwd(geom, qkv, cx, dcx, lse, valid=valid)

@@ -717,6 +717,20 @@ def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sa
     return dx
 
 
+def layernorm_bwd_dropout(dy, x, gamma_p, beta_p, mean, rstd, p, seed):
+    """-> (dx, dropout(dx, p, seed)): layernorm_bwd with the backward hidden dropout written by the same pass (mvuld_layernorm_bwd_drop:
+    same mask, same bits as the two launches)."""
+    rows, C = x.shape
+    if not (USE_LN_DROP[0] and p > 0.0 and x.dtype == torch.bfloat16 and C % 8 == 0 and x.is_contiguous() and dy.is_contiguous()):
+        dx = layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd)
+        return dx, dropout(dx, p, seed)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    ws = _workspace(x.device, hip.LIB.fn("mvuld_layernorm_bwd_workspace_bytes")(C))
+    call("layernorm_bwd_drop", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(dx), ptr(dxd), ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)),
+         rows, C, ptr(ws), ws.numel() * 4, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, rng_offset_ptr())
+    return dx, dxd
+
+
 def batchnorm_fwd(x, gamma, beta, run_mean, run_var, O, C, I, so, sc, si, training, eps=1e-5, momentum=0.1):
     y = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)

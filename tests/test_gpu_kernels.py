@@ -928,6 +928,22 @@ def test_layernorm_with_fused_hidden_dropout_is_bit_identical(gpu, rows, C):
             ops.USE_LN_DROP[0] = True
         assert torch.equal(y1, y0) and torch.equal(s1, s0) and torch.equal(m1, m0) and torch.equal(r1, r0)
         assert not torch.equal(s1, (x.float() + pre.float()).to(torch.bfloat16))          # the mask did something
+        # ... and the backward: mvuld_layernorm_bwd_drop = layernorm_bwd + dropout of its output, one pass, the same bits (parameter
+        # gradients included: the column sums do not see the mask)
+        gp = [torch.nn.Parameter(gamma.clone()), torch.nn.Parameter(beta.clone())]
+        outs = []
+        for fused in (True, False):
+            ops.USE_LN_DROP[0] = fused
+            try:
+                for q in gp:
+                    q.grad = torch.zeros_like(q)
+                dx, dxd = ops.layernorm_bwd_dropout(pre, s1, gp[0], gp[1], m1, r1, p, seed + 1)
+                outs.append((dx, dxd, gp[0].grad.clone(), gp[1].grad.clone()))
+            finally:
+                ops.USE_LN_DROP[0] = True
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][:2], outs[1][:2]))
+        assert all(rel(a, b) < 1e-6 for a, b in zip(outs[0][2:], outs[1][2:]))
+        assert float((outs[0][1] == 0).float().mean()) > 0.5 * p and not torch.equal(outs[0][0], outs[0][1])
 
 
 @pytest.mark.parametrize("M,C", [(6272, 128), (1000, 128), (3136, 256), (777, 256), (70000, 128)])
