@@ -175,6 +175,15 @@ int mvuld_layernorm_fwd_drop(const void* x, const void* pre, void* xsum, const f
 int mvuld_layernorm_bwd_drop(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, void* dxd,
                              float* dgamma, float* dbeta, int64_t rows, int C, float* ws, int64_t ws_bytes, float drop_p, uint64_t drop_seed,
                              const uint64_t* seed_offset, mvuld_stream_t stream);
+/* Deferred LayerNorm parameter gradients: mvuld_layernorm_bwd (or _drop) with dgamma = dbeta = NULL and a workspace writes dx and
+ * nparts = mvuld_layernorm_bwd_nparts(rows, C, ws_bytes, dtype) rows of column partials into ws ([nparts][2C] floats; 0 = this call
+ * would not take the partial form: pass the gradients instead), and mvuld_layernorm_bwd_reduce adds them into dgamma / dbeta later --
+ * on any stream ordered after the first call (the caller keeps ws alive and unshared until then).  Nothing in backward reads these
+ * gradients; launched on the backward chain the 5 us reduction costs the step ~25 us beside other streams' kernels. */
+int mvuld_layernorm_bwd_nparts(int64_t rows, int C, int64_t ws_bytes, int dtype);
+int mvuld_layernorm_bwd_reduce(const float* ws, int nparts, int C, float* dgamma, float* dbeta, mvuld_stream_t stream);
+/* ... any number of them in one launch per 64: desc = njobs x 5 int64 {ws, nparts, C, dgamma, dbeta}, read on the host during the call */
+int mvuld_layernorm_bwd_reduce_batch(const int64_t* desc, int njobs, mvuld_stream_t stream);
 /* dx for the normalised input (x, or xsum when `pre` was used); dgamma/dbeta accumulate (+=).  `ws` (optional, fp32,
  * ws_bytes >= 512*C) lends room for per-block column partials summed by a second kernel; without it the column sums
  * are device atomics (slower: ~1.5M contended atomics per launch at C=768). */

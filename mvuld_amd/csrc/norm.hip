@@ -653,3 +653,71 @@ extern "C" int mvuld_batchnorm_bwd(const void* dy, const void* x, const float* g
 /* bytes of fp32 scratch mvuld_layernorm_bwd wants for its two-pass column sums (1024 blocks x 2C floats) */
 extern "C" int64_t mvuld_layernorm_bwd_workspace_bytes(int C) { return (int64_t)1024 * 2 * (C > 0 ? C : 0) * 4; }
 
+// Deferred parameter gradients.  mvuld_layernorm_bwd called with dgamma = dbeta = NULL and a workspace writes dx and the per-workgroup
+// column partials only (ws[p][0..C) = d gamma, ws[p][C..2C) = d beta, p < nparts) and launches nothing else; the caller adds them into the
+// gradients whenever it likes -- on another stream, off the backward chain: nothing in backward reads a LayerNorm's parameter gradients, and
+// a 5 us reduction launched between two chip-filling kernels costs the chain far more than 5 us beside other streams' kernels.
+extern "C" int mvuld_layernorm_bwd_nparts(int64_t rows, int C, int64_t ws_bytes, int dtype) {
+    if (dtype != MVULD_BF16 || rows <= 0 || C <= 0 || C % 8 != 0 || C > 64 * LN_MAXPL || ws_bytes < (int64_t)8 * C * 64) return 0;
+    const int G = ln_group(C), rpw = 64 / G;
+    static const int capv = getenv("MVULD_LN_BWD_GRID") ? atoi(getenv("MVULD_LN_BWD_GRID")) : 1024;
+    int gridv = (int)min((int64_t)capv, cdiv(rows, (int64_t)4 * rpw));
+    return (int)min((int64_t)gridv, ws_bytes / ((int64_t)8 * C));
+}
+// ... and many of them in ONE launch (job table as a kernel argument): blockIdx.z = job, blockIdx.y = slab of partial rows, blockIdx.x = 64 columns
+// of [d gamma | d beta].  Small workgroups on purpose: beside the step's persistent GEMMs (one 512-thread, 256-register workgroup per CU) a
+// 1024-thread workgroup finds no CU with room until one of those kernels ends, and stalls its stream that long.
+#define LN_RED_MAX_JOBS 64
+struct LnRedJobs { int n; struct { const float* ws; float* dg; float* db; int nparts, C; } j[LN_RED_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_batch_k(const LnRedJobs J) {
+    __shared__ float red[4][64];
+    const auto& jb = J.j[blockIdx.z];
+    const int C = jb.C, nblk = jb.nparts;
+    if ((int)blockIdx.x * 64 >= 2 * C) return;                 // (uniform: narrower job than the widest of the launch)
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int cc = min(c, 2 * C - 1);
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0 + g; b < b1; b += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + 4 * u;
+            const float v = jb.ws[(size_t)min(bb, nblk - 1) * 2 * C + cc];
+            a[u] += bb < b1 ? v : 0.f;
+        }
+    }
+    red[g][threadIdx.x & 63] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (g == 0 && c < 2 * C) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (c < C) { if (jb.dg) atomicAdd(jb.dg + c, t); }
+        else if (jb.db) atomicAdd(jb.db + c - C, t);
+    }
+}
+// desc: njobs x 5 int64 {ws, nparts, C, dgamma, dbeta}, read on the host during the call
+extern "C" int mvuld_layernorm_bwd_reduce_batch(const int64_t* desc, int njobs, hipStream_t stream) {
+    MV_CHECK_ARG(desc && njobs > 0, "layernorm_bwd_reduce_batch: bad args");
+    for (int i0 = 0; i0 < njobs; i0 += LN_RED_MAX_JOBS) {
+        LnRedJobs J;
+        J.n = min(LN_RED_MAX_JOBS, njobs - i0);
+        int cmax = 0;
+        for (int i = 0; i < J.n; ++i) {
+            const int64_t* d = desc + 5 * (i0 + i);
+            MV_CHECK_ARG(d[0] && d[1] > 0 && d[2] > 0 && (d[3] || d[4]), "layernorm_bwd_reduce_batch: job %d: bad entry", i0 + i);
+            J.j[i].ws = (const float*)d[0]; J.j[i].nparts = (int)d[1]; J.j[i].C = (int)d[2]; J.j[i].dg = (float*)d[3]; J.j[i].db = (float*)d[4];
+            cmax = max(cmax, (int)d[2]);
+        }
+        hipLaunchKernelGGL(layernorm_bwd_reduce_batch_k, dim3(cdiv(2 * cmax, 64), 16, J.n), dim3(256), 0, stream, J);
+    }
+    MV_LAUNCH_CHECK("layernorm_bwd_reduce_batch");
+    return 0;
+}
+
+extern "C" int mvuld_layernorm_bwd_reduce(const float* ws, int nparts, int C, float* dgamma, float* dbeta, hipStream_t stream) {
+    MV_CHECK_ARG(ws && nparts > 0 && C > 0 && (dgamma || dbeta), "layernorm_bwd_reduce: bad args");
+    hipLaunchKernelGGL(layernorm_bwd_reduce_k, dim3(cdiv(2 * C, 64), 8), dim3(1024), 0, stream, ws, nparts, C, dgamma, dbeta);
+    MV_LAUNCH_CHECK("layernorm_bwd_reduce");
+    return 0;
+}
+

@@ -42,6 +42,7 @@ def fire_backward_done(tag):
     # close the group) must be in flight before anything that reads the gradients (the data-parallel exchange) is launched
     if _WGRAD_PENDING[0]:
         wgrad_group_flush()
+    ln_reduce_flush()
     cbs = list(_BACKWARD_DONE.get(tag, {}).values())
     if (cbs or tag == "swin") and tag.startswith("swin"):
         join_wgrad_stream()               # the image encoder's weight gradients run on their own stream: finish them first
@@ -471,6 +472,7 @@ def wgrad_stream_for_current():
 
 def join_wgrad_stream():
     """Make the current stream wait for every weight gradient issued so far (before anything reads them: all-reduce, optimizer)."""
+    ln_reduce_flush()
     ws = WGRAD_STREAM[0]
     if ws is not None:
         ev = torch.cuda.Event()
@@ -500,6 +502,39 @@ def _tn_workspace(device, nbytes):
 # block changes no dependency; operands stay referenced by the pending list until the launch.
 USE_WGRAD_GROUPS = [os.environ.get("MVULD_WGRAD_GROUP", "1") != "0"]
 _WGRAD_PENDING = [None]
+# LayerNorm parameter gradients, deferred further (layernorm_bwd): (partials, nparts, C, dgamma, dbeta, producing stream).  While the image encoder's weight
+# gradients go to the weight-gradient stream, a LayerNorm backward writes its column partials into a buffer of its own and the reductions
+# that add them into the gradients are issued TOGETHER, one launch for the whole encoder (or stage, under data parallelism), when its
+# backward-done hook fires.  Measured (bench.py, 60 steps): the 48 per-LayerNorm reduction launches cost the step 1.7-2.6 ms although they
+# run 5 us each alone -- their 1024-thread workgroups found no CU with room beside the persistent GEMMs of the other streams.
+USE_LN_DEFER = [os.environ.get("MVULD_LN_DEFER", "1") != "0"]
+_LN_PENDING = []
+
+
+def ln_reduce_flush():
+    """Issue the pending LayerNorm parameter-gradient reductions in one launch (on the weight-gradient stream when one is active)."""
+    if not _LN_PENDING:
+        return
+    lns = list(_LN_PENDING)
+    del _LN_PENDING[:]
+    import ctypes
+    dev = lns[0][0].device
+    wg = wgrad_stream_for_current()
+    dst = wg if wg is not None else torch.cuda.current_stream(dev)
+    seen = set()
+    for part, nparts, C, dg, db, src in lns:               # order the launch behind every stream that produced partials
+        if src.cuda_stream != dst.cuda_stream and src.cuda_stream not in seen:
+            seen.add(src.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(src)
+            dst.wait_event(ev)
+        if src.cuda_stream != dst.cuda_stream:
+            part.record_stream(dst)
+    desc = (ctypes.c_int64 * (5 * len(lns)))()
+    for k, (part, nparts, C, dg, db, src) in enumerate(lns):
+        desc[5 * k:5 * k + 5] = [part.data_ptr(), nparts, C, dg.data_ptr(), db.data_ptr()]
+    with torch.cuda.stream(dst):
+        call("layernorm_bwd_reduce_batch", ctypes.addressof(desc), len(lns))
 
 
 class wgrad_group:
@@ -708,9 +743,28 @@ def layernorm_dropout_fwd(x, gamma, beta, eps, pre, p, seed, want_sum=True):
     return y, mean, rstd, xsum
 
 
+def _ln_defer(x, rows, C):
+    """(partials buffer, nparts) when this LayerNorm backward's parameter gradients can leave the chain: while a weight-gradient stream
+    is active for the current stream (the fused step's image encoder: ops.fire_backward_done flushes); else None."""
+    if not (USE_LN_DEFER[0] and wgrad_stream_for_current() is not None):
+        return None
+    nbytes = hip.LIB.fn("mvuld_layernorm_bwd_workspace_bytes")(C)
+    nparts = hip.LIB.fn("mvuld_layernorm_bwd_nparts")(rows, C, nbytes, dt(x))
+    if nparts <= 0:
+        return None
+    return torch.empty(max(nparts, 64) * 2 * C, dtype=torch.float32, device=x.device), nparts      # (>= 64 rows: the size that selects the partial form)
+
+
 def layernorm_bwd(dy, x, gamma_p, beta_p, mean, rstd, rowscale=None, rows_per_sample=1):
     rows, C = x.shape
     dx = torch.empty_like(x)
+    d = _ln_defer(x, rows, C)
+    if d is not None:
+        part, nparts = d
+        call("layernorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(rowscale), rows_per_sample, ptr(dx),
+             None, None, rows, C, ptr(part), part.numel() * 4, dt(x))
+        _LN_PENDING.append((part, nparts, C, grad_of(gamma_p), grad_of(beta_p), torch.cuda.current_stream(x.device)))
+        return dx
     ws = _workspace(x.device, hip.LIB.fn("mvuld_layernorm_bwd_workspace_bytes")(C))
     call("layernorm_bwd", ptr(dy), ptr(x), ptr(gamma_p), ptr(mean), ptr(rstd), ptr(rowscale), rows_per_sample, ptr(dx),
          ptr(grad_of(gamma_p)), ptr(grad_of(beta_p)), rows, C, ptr(ws), ws.numel() * 4, dt(x))

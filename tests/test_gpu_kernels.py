@@ -946,6 +946,54 @@ def test_layernorm_with_fused_hidden_dropout_is_bit_identical(gpu, rows, C):
         assert float((outs[0][1] == 0).float().mean()) > 0.5 * p and not torch.equal(outs[0][0], outs[0][1])
 
 
+@pytest.mark.parametrize("rows,C", [(6272, 512), (1568, 1024), (25088, 128), (333, 256)])
+def test_layernorm_backward_with_deferred_parameter_gradients(gpu, rows, C):
+    """While a weight-gradient stream is active, layernorm_bwd writes dx and its column partials only; the reductions into d gamma / d beta
+    are issued together, in one launch on that stream, when the encoder's backward-done hook fires or the stream is joined
+    (mvuld_layernorm_bwd_nparts / _reduce_batch).  Same dx bits, same gradients, nothing added before the flush, several LayerNorms per
+    launch, and a second round accumulates on top."""
+    from mvuld_amd import ops
+    g_ = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g_).to(torch.bfloat16).to(gpu)
+    dy = torch.randn(rows, C, generator=g_).to(torch.bfloat16).to(gpu)
+    gamma, beta = torch.nn.Parameter((torch.rand(C, generator=g_) + 0.5).to(gpu)), torch.nn.Parameter(torch.randn(C, generator=g_).to(gpu))
+    _, mean, rstd, _ = ops.layernorm_fwd(x, gamma.data, beta.data, 1e-5)[:4]
+    for q in (gamma, beta):
+        q.grad = torch.zeros_like(q)
+    dx0 = ops.layernorm_bwd(dy, x, gamma, beta, mean, rstd)                    # no group: reduction launched at once
+    g0, b0 = gamma.grad.clone(), beta.grad.clone()
+    assert float(g0.abs().max()) > 0
+    main, wg = torch.cuda.current_stream(gpu), torch.cuda.Stream(device=gpu)
+    assert ops.USE_LN_DEFER[0] and ops.WGRAD_STREAM[0] is None
+    ops.WGRAD_STREAM[0] = (main.cuda_stream, wg)
+    try:
+        g2, b2 = torch.nn.Parameter(gamma.data.clone()), torch.nn.Parameter(beta.data.clone())      # a second LayerNorm in the same launch
+        g2.grad, b2.grad = torch.zeros_like(g2), torch.zeros_like(b2)
+        for rep in (1, 2):
+            if rep == 1:
+                gamma.grad.zero_(); beta.grad.zero_()
+            dx1 = ops.layernorm_bwd(dy, x, gamma, beta, mean, rstd)
+            dx2 = ops.layernorm_bwd(dx0, x, g2, b2, mean, rstd)
+            assert len(ops._LN_PENDING) == 2
+            torch.cuda.synchronize()
+            assert rel(gamma.grad, (rep - 1) * g0) < 1e-6 if rep == 2 else float(gamma.grad.abs().max()) == 0.0      # not yet
+            ops.join_wgrad_stream()
+            assert not ops._LN_PENDING
+            torch.cuda.synchronize()
+            assert torch.equal(dx1, dx0)
+            assert rel(gamma.grad, rep * g0) < 1e-6 and rel(beta.grad, rep * b0) < 1e-6
+        ops.USE_LN_DEFER[0] = False
+        try:
+            r2, rb2 = torch.nn.Parameter(gamma.data.clone()), torch.nn.Parameter(beta.data.clone())
+            r2.grad, rb2.grad = torch.zeros_like(r2), torch.zeros_like(rb2)
+            assert torch.equal(ops.layernorm_bwd(dx0, x, r2, rb2, mean, rstd), dx2)
+            assert rel(g2.grad, 2 * r2.grad) < 1e-6 and rel(b2.grad, 2 * rb2.grad) < 1e-6
+        finally:
+            ops.USE_LN_DEFER[0] = True
+    finally:
+        ops.WGRAD_STREAM[0] = None
+
+
 @pytest.mark.parametrize("M,C", [(6272, 128), (1000, 128), (3136, 256), (777, 256), (70000, 128)])
 def test_fused_mlp_panel_kernels(gpu, M, C):
     """Round 3, csrc/mlp_panel.hip (Mlp.forward swin_transformer_v2.py:26-32 and its autograd at C = 128 / 256): the fused forward
