@@ -233,6 +233,10 @@ int mvuld_set_attn_tail_split(int on);
  * kernel's to bf16 rounding), 2 = on the general kernel's exact schedule (bit-identical to it), 0 = the general kernel
  * (MVULD_ATTN_WIN). */
 int mvuld_set_attn_win(int mode);
+/* 1 (default): in shifted blocks, the forward, dQ and dK/dV passes skip the tiles whose pairs all lie across the vertical
+ * mask split of a last-row window (each carries the -100 of swin_transformer_v2.py:245-268 and is < 2^-57 of its row's largest
+ * probability while tau <= 22; heads with a larger tau compute every pair); 0: nothing is skipped.  Same output bits.  Env: MVULD_ATTN_YSKIP. */
+int mvuld_set_attn_yskip(int on);
 /* The same attention on the matrix cores (bf16 storage only; v_mfma_f32_16x16x32_bf16, K / V^T (forward), K / K^T / V (dQ pass)
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
  * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).

@@ -33,6 +33,9 @@ struct AttnGeom {
     // Tail balancing (am_plan): the first `whole` workgroups (in launch order) take one (window, head) each, the workgroups behind them
     // split the remaining ones `split` ways; whole = 0: every (window, head) is split `split` ways.
     int whole = 0;
+    // MODE 0, shifted windows: skip the key blocks (query blocks) that lie wholly across a window's vertical mask split from the wave's
+    // queries (keys) -- every pair in them carries the -100 of swin_transformer_v2.py:245-268 (am_ysplit); 0 = compute them as every other pair
+    int yskip = 0;
 };
 __device__ __forceinline__ unsigned am_seed(const AttnGeom& g) {
     return g.drop_off ? g.drop_seed ^ (unsigned)(g.drop_off[0] * 0x9E3779B97F4A7C15ULL >> 32) : g.drop_seed;
@@ -96,6 +99,21 @@ __device__ __forceinline__ bool am_window_masked(const AttnGeom& g, int w) {
     const int nwx = g.res / g.ws;
     return g.shift > 0 && ((w / nwx) == nwx - 1 || (w % nwx) == nwx - 1);
 }
+// The last ROW of windows of a shifted block holds two vertical mask regions: window rows below ws - shift come from the bottom of the
+// image, the rest from its (rolled-in) top, and the -100 on every pair across the split leaves them exp2(-144 + (s - m)) of the row's
+// largest probability.  With cosine logits |q.k| <= tau and a bias in (0, 16) that is below 2^-57 for tau <= 22: under the fp32
+// resolution of every accumulator it would be added to, so whole tiles of such pairs are skipped -- same bits out -- while a head whose tau
+// has grown past the bound keeps computing them (as the reference's finite -100 demands).  Returns the split as a token index of the
+// window's row-major order, or INT_MAX (no split in this window / tau too large / switched off).  The horizontal split of the last
+// COLUMN of windows cannot be skipped tile-wise: every 16-token tile of a row-major window holds tokens of both of its sides.
+#define AM_YSKIP_TAU 22.0f
+__device__ __forceinline__ int am_ysplit(const AttnGeom& g, int w, float tau) {
+    const int nwx = g.res / g.ws;
+    if (g.mode != 0 || g.shift <= 0 || !g.yskip || !(tau <= AM_YSKIP_TAU) || (w / nwx) != nwx - 1) return 0x7fffffff;
+    return (g.ws - g.shift) * g.ws;
+}
+// query tokens [q0, q1) and key tokens [k0, k1) on opposite sides of the split
+__device__ __forceinline__ bool am_yskip(int ys, int q0, int q1, int k0, int k1) { return (q1 <= ys && k0 >= ys) || (q0 >= ys && k1 <= ys); }
 // per-token info word.  MODE 0: (iy*(2ws-1)+ix) | region << 16 ; MODE 1: validity in bit 0.  Bit 30 marks a padding row
 // (all other fields then hold safe in-range values, so the hot loops stay branch-free).
 #define AM_PAD (1 << 30)
@@ -558,6 +576,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const int nfull64 = (g.N / 64) * 64;
     const bool g4 = MODE == 0 && (g.ws & 3) == 0;
     const bool wmask = MASK && am_window_masked(g, w);
+    const int ysp = am_ysplit(g, w, tau);
     // MODE 0 (hd = 32 windows): two query tiles per wave and 32-key blocks; the text encoder keeps one tile and 64-key blocks
     // (its K/V image at hd = 64 leaves no registers for a second tile's accumulators)
     constexpr int QT = (MODE == 0 && HD == 32) ? 2 : 1;
@@ -618,14 +637,19 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
             for (int d = 0; d < HD / 16; ++d) dq[q][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
         int kb = 0;
+        const int q0 = item * QT * 16, q1 = min(q0 + QT * 16, g.N);              // wave-uniform
         if (QT == 2) {
 #define AM_DQ2_SWEEP(MK)                                                                                                                       \
             if (g4) {                                                                                                                          \
-                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MK, false, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
-                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);      \
+                for (; kb < nfull32; kb += 32) { if (MK && am_yskip(ysp, q0, q1, kb, kb + 32)) continue;                                       \
+                    am_dq_block<HD, MODE, MK, false, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); } \
+                for (; kb < Np; kb += 32) { if (MK && am_yskip(ysp, q0, q1, kb, g.N)) continue;                                                \
+                    am_dq_block<HD, MODE, MK, true, 2, true, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); } \
             } else {                                                                                                                           \
-                for (; kb < nfull32; kb += 32) am_dq_block<HD, MODE, MK, false, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); \
-                for (; kb < Np; kb += 32) am_dq_block<HD, MODE, MK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb);     \
+                for (; kb < nfull32; kb += 32) { if (MK && am_yskip(ysp, q0, q1, kb, kb + 32)) continue;                                       \
+                    am_dq_block<HD, MODE, MK, false, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); } \
+                for (; kb < Np; kb += 32) { if (MK && am_yskip(ysp, q0, q1, kb, g.N)) continue;                                                \
+                    am_dq_block<HD, MODE, MK, true, 2, false, false, QT>(Ks, Vs, Kinfo, kb, qf, dof, tabq, regq, vq, L2q, negD, lane, dq, eb); } \
             }
             if (MASK && wmask) { AM_DQ2_SWEEP(true) } else { AM_DQ2_SWEEP(false) }
 #undef AM_DQ2_SWEEP
@@ -1048,6 +1072,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 
     const bool g4 = MODE == 0 && (g.ws & 3) == 0;
     const bool wmask = MASK && am_window_masked(g, w);
+    const int ysp = am_ysplit(g, w, MODE == 0 ? qmul : 0.f);
     const int ntile = (g.N + 15) / 16;
     const int nfull64 = (g.N / 64) * 64;
     for (int kt = part + ksplit * wave; kt < ntile; kt += ksplit * (blockDim.x >> 6)) {
@@ -1081,6 +1106,7 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
 #pragma unroll
         for (int d = 0; d < HD / 16; ++d) { dk[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
         int qb = 0;
+        const int k0 = kt * 16, k1 = min(k0 + 16, g.N);                         // this wave's keys (wave-uniform)
         if (MODE == 1 && drop) {
             const unsigned NLh = (NL + 1) >> 1;
             const unsigned eb = (unsigned)lse0 * NLh + ((unsigned)nk >> 1);      // (b, h) row block + this lane's key PAIR (unclamped: neighbours agree); + q * NLh per query
@@ -1091,11 +1117,15 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
         } else {
 #define AM_DKV_SWEEP(MK)                                                                                                                       \
             if (g4) {                                                                                                                          \
-                for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); \
-                for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);      \
+                for (; qb < nfull64; qb += 64) { if (MK && am_yskip(ysp, qb, qb + 64, k0, k1)) continue;                                       \
+                    am_dkv_block<HD, MODE, MK, false, 4, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); }               \
+                for (; qb < Np; qb += 32) { if (MK && am_yskip(ysp, qb, g.N, k0, k1)) continue;                                               \
+                    am_dkv_block<HD, MODE, MK, true, 2, true>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); }                \
             } else {                                                                                                                           \
-                for (; qb < nfull64; qb += 64) am_dkv_block<HD, MODE, MK, false, 4, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); \
-                for (; qb < Np; qb += 32) am_dkv_block<HD, MODE, MK, true, 2, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv);     \
+                for (; qb < nfull64; qb += 64) { if (MK && am_yskip(ysp, qb, qb + 64, k0, k1)) continue;                                       \
+                    am_dkv_block<HD, MODE, MK, false, 4, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); }              \
+                for (; qb < Np; qb += 32) { if (MK && am_yskip(ysp, qb, g.N, k0, k1)) continue;                                               \
+                    am_dkv_block<HD, MODE, MK, true, 2, false>(Qs, Ds, Qi, Ql, Qd, qb, kf, vf, tabk, regk, vk, lane, dk, dv); }               \
             }
             if (MASK && wmask) { AM_DKV_SWEEP(true) } else { AM_DKV_SWEEP(false) }
 #undef AM_DKV_SWEEP
@@ -1351,6 +1381,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_win_k(AttnGeom g, const bf16* _
     const int ntile = (g.N + 15) / 16, nitem = (ntile + QT - 1) / QT;
     const int nfull64 = (g.N / 64) * 64;
     const bool wmask = MASK && am_window_masked(g, w);
+    const int ysp = am_ysplit(g, w, tau);
     const unsigned tab0 = aw_lds(tab3);
     bf16x8_t ones;
 #pragma unroll
@@ -1390,8 +1421,15 @@ __global__ __launch_bounds__(1024) void attn_fwd_win_k(AttnGeom g, const bf16* _
         }
         int kb = 0;
         if (MASK && wmask) {
-            for (; kb < nfull64; kb += 64) aw_fwd_block<true, false, 4, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
-            for (; kb < Np; kb += 32) aw_fwd_block<true, true, 2, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+            const int q0 = item * QT * 16, q1 = min(q0 + QT * 16, g.N);          // wave-uniform
+            for (; kb < nfull64; kb += 64) {
+                if (am_yskip(ysp, q0, q1, kb, kb + 64)) continue;
+                aw_fwd_block<true, false, 4, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+            }
+            for (; kb < Np; kb += 32) {
+                if (am_yskip(ysp, q0, q1, kb, g.N)) continue;
+                aw_fwd_block<true, true, 2, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
+            }
         } else {
             for (; kb < nfull64; kb += 64) aw_fwd_block<false, false, 4, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
             for (; kb < Np; kb += 32) aw_fwd_block<false, true, 2, QT, LAZY>(Ks, Vs, Kinfo, Koff, kb, qf, tabq, regq, lane, m, lacc, oacc, ones);
@@ -1457,6 +1495,22 @@ static int am_split(int64_t groups, int ntile) {
 // MVULD_ATTN_TAIL_SPLIT / mvuld_set_attn_tail_split: 1 = balance the last round, 0 = off (default).  Measured on the text encoder's 384
 // groups: forward 73.3 vs 73.8 us, backward 177.9 vs 179.9 us, whole step 60.4 vs 60.2 ms -- re-staging K/V for the halves costs what the
 // emptier round saved, and beside other streams the half-empty round was never idle.  Bit-identical either way (tests).
+// Skipping of the tiles across a shifted window's vertical mask split (am_ysplit): MVULD_ATTN_YSKIP / mvuld_set_attn_yskip, 1 = on (default),
+// 0 = every pair is computed.  Bit-identical either way while tau <= 22 (tests); a head past that bound computes every pair regardless.
+static std::atomic<int> g_am_yskip{-1};
+extern "C" int mvuld_set_attn_yskip(int on) {
+    g_am_yskip.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+static int am_yskip_on() {
+    int v = g_am_yskip.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_ATTN_YSKIP");
+        v = (!e || atoi(e) != 0) ? 1 : 0;
+        g_am_yskip.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 static std::atomic<int> g_am_tail{-1};
 extern "C" int mvuld_set_attn_tail_split(int on) {
     g_am_tail.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -1537,6 +1591,7 @@ extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW
     MV_CHECK_ARG(qkv && out && lse && (mode >= 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_fwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
     AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
+    g.yskip = am_yskip_on();
     am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
@@ -1594,6 +1649,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     MV_CHECK_ARG(mode >= 1 ? valid != nullptr : (table16 && logit_scale && dtable16 && dlogit_scale && ws_qt), "attn_bwd_mfma: null pointer");
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_bwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
     AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
+    g.yskip = am_yskip_on();
     am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     int64_t ntok = (int64_t)B * nW * N;
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }

@@ -612,6 +612,41 @@ def test_window_fast_path_forward(gpu, res, ws, shift, H):
     assert bool(torch.isfinite(got[1][0].float()).all()) and bool(torch.isfinite(got[1][1]).all())
 
 
+@pytest.mark.parametrize("res,ws,shift,H,ls_hi", [(56, 28, 14, 2, 3.0), (112, 28, 14, 1, 3.0), (16, 8, 4, 2, 3.0), (24, 12, 6, 1, 3.0), (28, 14, 7, 2, 3.0),
+                                                  (56, 28, 14, 2, 5.0), (28, 28, 0, 2, 3.0)])
+def test_shifted_window_vertical_mask_split_skip_is_bit_identical(gpu, res, ws, shift, H, ls_hi):
+    """In a shifted block the windows of the last row hold two vertical mask regions; every pair across the split carries the -100 of
+    swin_transformer_v2.py:245-268.  The forward, dQ and dK/dV passes skip the tiles made of such pairs only (am_ysplit, heads
+    with tau <= 22: the skipped probabilities are < 2^-57 of their row's largest); mvuld_set_attn_yskip(0) computes every pair.  All
+    outputs must be EQUAL bit for bit (out, lse, dqkv) or to the rounding of their atomic sums (d(bias table), d(logit_scale)).  ls_hi = 5.0
+    draws heads past the tau bound (which must then compute every pair: equality again), shift 0 has no split."""
+    from mvuld_amd import ops, hip
+    B, hd = 2, 32
+    C = H * hd
+    T2 = (2 * ws - 1) ** 2
+    qkv = dev(rt(T("yq", (B * res * res, 3 * C), -2, 2), torch.bfloat16), torch.bfloat16)
+    dout = dev(rt(T("yd", (B * res * res, C)), torch.bfloat16), torch.bfloat16)
+    table, ls = dev(T("yt", (T2, H), 0.0, 16.0)), dev(T("yls", (H,), 1.5, ls_hi))
+    g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+    got = {}
+    try:
+        for on in (1, 0):
+            hip.LIB.fn("mvuld_set_attn_yskip")(on)
+            out, lse = ops.attn_fwd(g, qkv, table, ls)
+            dtab, dls = torch.zeros((T2, H), device=gpu), torch.zeros(H, device=gpu)
+            dqkv = ops.attn_bwd(g, qkv, out, dout, lse, table, ls, None, dtab, dls)
+            torch.cuda.synchronize()
+            got[on] = (out, lse, dqkv, dtab, dls)
+    finally:
+        hip.LIB.fn("mvuld_set_attn_yskip")(1)
+    names = ("out", "lse", "dqkv")
+    for n, a, b in zip(names, got[1][:3], got[0][:3]):
+        assert torch.equal(a, b), (n, rel(a, b))
+    # d(bias table) and d(logit_scale) are sums of float atomics (LDS / global), whose order is not fixed from run to run
+    assert rel(got[1][3], got[0][3]) < 1e-6 and rel(got[1][4], got[0][4]) < 1e-6
+    assert bool(torch.isfinite(got[1][2].float()).all())
+
+
 @pytest.mark.parametrize("dtype,impl", [(torch.float32, "simple"), (torch.bfloat16, "simple"), (torch.bfloat16, "auto")])
 @pytest.mark.parametrize("hd,L", [(32, 100), (64, 100), (64, 512)])
 def test_padmask_attention(gpu, dtype, impl, hd, L):
