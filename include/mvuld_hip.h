@@ -241,18 +241,22 @@ int mvuld_set_attn_yskip(int on);
  * and Q~ / dO and their transposes (dK,dV pass) staged in LDS).  ws_delta: caller-owned fp32 [tokens*H] workspace;
  * ws_qt: caller-owned bf16 [tokens, H*hd] workspace (mode 0: normalised queries shared between the dQ and bias-gradient passes).
  * ws_part (optional, mode 0): fp32 room for one (2ws-1)^2 partial bias-table gradient per workgroup of the bias pass
- * (<= B*nW*H*2 of them), summed by a second kernel; without it every workgroup adds its table with device atomics. */
+ * (<= B*nW*H*2 of them), summed by a second kernel; without it every workgroup adds its table with device atomics.
+ * sample_scale (optional, mode 0): [B] fp32, the per-sample DropPath factor of the residual branch this attention feeds
+ * (swin_transformer_v2.py:301: x = shortcut + drop_path(norm1(attn))).  A sample whose factor is exactly 0 contributes nothing to
+ * the block's output or to any gradient, so its workgroups write zeros (out, lse; dqkv) and add nothing to the table gradient
+ * instead of computing them -- stochastic depth as a saving, the same values downstream.  Pass the SAME vector to both calls. */
 int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
-                        void* out, float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype,
-                        mvuld_stream_t stream);
+                        void* out, float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset,
+                        const float* sample_scale, int dtype, mvuld_stream_t stream);
 int64_t mvuld_attn_bwd_mfma_workspace_bytes(int mode, int B, int H, int nW, int ws);   /* size of `ws_part` */
 int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                         const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                         const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                         float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes,
-                        int passes, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype,
-                        mvuld_stream_t stream);
+                        int passes, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset,
+                        const float* sample_scale, int dtype, mvuld_stream_t stream);
 /* passes: 1 = delta + dQ + dK/dV, 2 = bias-table gradient (mode 0; reads ws_delta / ws_qt written by pass 1), 3 = both.
  * The bias-table gradient feeds nothing else in backward, so a caller may issue pass 2 later, on another stream. */
 

@@ -36,7 +36,12 @@ struct AttnGeom {
     // MODE 0, shifted windows: skip the key blocks (query blocks) that lie wholly across a window's vertical mask split from the wave's
     // queries (keys) -- every pair in them carries the -100 of swin_transformer_v2.py:245-268 (am_ysplit); 0 = compute them as every other pair
     int yskip = 0;
+    // MODE 0, optional [B] per-sample scale of the residual branch this attention belongs to (DropPath, swin_transformer_v2.py:301): a sample
+    // whose scale is exactly 0 contributes nothing downstream (forward: its output is multiplied by 0; backward: its d(out) IS 0), so its
+    // workgroups write zeros and return instead of computing them
+    const float* sscale = nullptr;
 };
+__device__ __forceinline__ bool am_dropped(const AttnGeom& g, int b) { return g.mode == 0 && g.sscale != nullptr && g.sscale[b] == 0.f; }
 __device__ __forceinline__ unsigned am_seed(const AttnGeom& g) {
     return g.drop_off ? g.drop_seed ^ (unsigned)(g.drop_off[0] * 0x9E3779B97F4A7C15ULL >> 32) : g.drop_seed;
 }
@@ -371,6 +376,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_mfma_k(AttnGeom g, const bf16* 
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    if (MODE == 0 && am_dropped(g, b)) {                     // workgroup-uniform: zeros where this workgroup would have written
+        const int ntile0 = (g.N + 15) / 16;
+        for (int qt = part + qsplit * wave; qt < ntile0; qt += qsplit * (blockDim.x >> 6)) {
+            const int nq = qt * 16 + fc;
+            if (nq < g.N) {
+                const int64_t t = am_token(g, b, w, nq);
+#pragma unroll
+                for (int d = 0; d < HD / 16; ++d) *(uint2*)(out + t * C + h * HD + d * 16 + 4 * fg) = make_uint2(0, 0);
+                if (fg == 0) lse[lse0 + nq] = 0.f;
+            }
+        }
+        return;
+    }
     const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
 
@@ -553,6 +571,21 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    if (MODE == 0 && am_dropped(g, b)) {                     // d(out) of this sample is zero: so is dQ (workgroup-uniform)
+        constexpr int QT0 = HD == 32 ? 2 : 1;
+        const int ntile0 = (g.N + 15) / 16, nitem0 = (ntile0 + QT0 - 1) / QT0;
+        for (int item = part + qsplit * wave; item < nitem0; item += qsplit * (blockDim.x >> 6))
+#pragma unroll
+            for (int q = 0; q < QT0; ++q) {
+                const int nq = (item * QT0 + q) * 16 + fc;
+                if (item * QT0 + q < ntile0 && nq < g.N) {
+                    const int64_t t = am_token(g, b, w, nq);
+#pragma unroll
+                    for (int d = 0; d < HD / 16; ++d) *(uint2*)(dqkv + t * rs + h * HD + d * 16 + 4 * fg) = make_uint2(0, 0);
+                }
+            }
+        return;
+    }
     const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
 
@@ -763,10 +796,13 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // item / dy / key-row arithmetic stays scalar
     const int ws = g.ws;
 
-    stage_tile<HD, false>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);          // padded rows: b128 reads only here
-    stage_tile<HD, false>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
-    for (int i = threadIdx.x; i < Npad; i += blockDim.x) Ktok[i] = (int)am_token(g, b, w, min(i, g.N - 1));
-    for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = table16[(int64_t)i * g.H + h] * LOG2E; dtab[i] = 0.f; }
+    const bool dropped = am_dropped(g, b);                   // workgroup-uniform: dS of this sample is zero, its table share too
+    if (!dropped) {
+        stage_tile<HD, false>(g, qkv, rs, C + h * HD, b, w, 0, Npad, Ks, true, 1.0f);          // padded rows: b128 reads only here
+        stage_tile<HD, false>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Npad, Vs, false, 1.0f);
+        for (int i = threadIdx.x; i < Npad; i += blockDim.x) Ktok[i] = (int)am_token(g, b, w, min(i, g.N - 1));
+    }
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) { tab[i] = dropped ? 0.f : table16[(int64_t)i * g.H + h] * LOG2E; dtab[i] = 0.f; }
     __syncthreads();
 
     const int nqp = (ws + 15) / 16;               // q parts per image row
@@ -778,7 +814,7 @@ __global__ __launch_bounds__(G >= 4 ? 512 : 1024) void attn_bwd_dbias_mfma_k(Att
     const bf16* do_h = dout + h * HD + fg * 8;
     const float* lse_h = lse + ((int64_t)bw * g.H + h) * g.N;
     const float* dl_h = delta + h;
-    for (int item = part + split * wave; item < nitem; item += split * (blockDim.x >> 6)) {
+    for (int item = part + split * wave; item < (dropped ? 0 : nitem); item += split * (blockDim.x >> 6)) {
         const int grp = item / nqp, qp = item % nqp;
         const int xq = qp * qw + fc;
         const bool qv = fc < qw && xq < ws;
@@ -1045,6 +1081,21 @@ __global__ __launch_bounds__((HD == 32 || MODE == 1) ? 1024 : 512) void attn_bwd
     const unsigned NL = (unsigned)g.N;
     const int Np = am_localize(g, b, Npad);
     if (Np == 0) return;
+    if (MODE == 0 && am_dropped(g, b)) {                     // d(out) of this sample is zero: so are dK and dV (workgroup-uniform)
+        const int ntile0 = (g.N + 15) / 16;
+        for (int kt = part + ksplit * wave; kt < ntile0; kt += ksplit * (blockDim.x >> 6)) {
+            const int nk = kt * 16 + fc;
+            if (nk < g.N) {
+                const int64_t t = am_token(g, b, w, nk);
+#pragma unroll
+                for (int d = 0; d < HD / 16; ++d) {
+                    *(uint2*)(dqkv + t * rs + C + h * HD + d * 16 + 4 * fg) = make_uint2(0, 0);
+                    *(uint2*)(dqkv + t * rs + 2 * C + h * HD + d * 16 + 4 * fg) = make_uint2(0, 0);
+                }
+            }
+        }
+        return;
+    }
     const bool drop = MODE == 1 && g.drop_inv != 1.0f;
     const unsigned dseed = drop ? am_seed(g) : 0u;
     int C0 = 0;
@@ -1367,6 +1418,21 @@ __global__ __launch_bounds__(1024) void attn_fwd_win_k(AttnGeom g, const bf16* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fc = lane & 15, fg = lane >> 4;
     const int64_t lse0 = ((int64_t)bw * g.H + h) * g.N;
     const int Np = Npad;
+    if (am_dropped(g, b)) {                                  // workgroup-uniform: zeros where this workgroup would have written
+        const int ntile0 = (g.N + 15) / 16, nitem0 = (ntile0 + QT - 1) / QT;
+        for (int item = part + qsplit * wave; item < nitem0; item += qsplit * (blockDim.x >> 6))
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const int nq = (item * QT + q) * 16 + fc;
+                if (item * QT + q < ntile0 && nq < g.N) {
+                    const int64_t t = am_token(g, b, w, nq);
+                    *(uint2*)(out + t * C + h * HD + 4 * fg) = make_uint2(0, 0);
+                    *(uint2*)(out + t * C + h * HD + 16 + 4 * fg) = make_uint2(0, 0);
+                    if (fg == 0) lse[lse0 + nq] = 0.f;
+                }
+            }
+        return;
+    }
 
     stage_tile<HD>(g, qkv, rs, C + h * HD, b, w, 0, Np, Ks, true, 1.0f);
     stage_tile<HD>(g, qkv, rs, 2 * C + h * HD, b, w, 0, Np, Vs, false, 1.0f);
@@ -1585,13 +1651,15 @@ static void am_set_dropout(AttnGeom& g, int mode, float p, uint64_t seed, const 
 
 extern "C" int mvuld_attn_fwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift, float scale,
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid, void* out,
-                                   float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
+                                   float* lse, float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, const float* sample_scale, int dtype,
+                                   hipStream_t stream) {
     if (am_check("attn_fwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_fwd_mfma: bf16 storage only");
     MV_CHECK_ARG(qkv && out && lse && (mode >= 1 ? valid != nullptr : (table16 && logit_scale)), "attn_fwd_mfma: null pointer");
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_fwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
     AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
     g.yskip = am_yskip_on();
+    g.sscale = mode == 0 ? sample_scale : nullptr;
     am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; }      // packed sequences: `valid` carries cu_seqlens [B + 1]
     const int Npad = (N + 31) / 32 * 32;
@@ -1641,7 +1709,8 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
                                    const void* qkv, const float* table16, const float* logit_scale, const int* valid,
                                    const void* out, const void* dout, const float* lse, void* dqkv, float* dtable16,
                                    float* dlogit_scale, float* ws_delta, void* ws_qt, float* ws_part, int64_t ws_part_bytes, int passes,
-                                   float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
+                                   float attn_drop_p, uint64_t drop_seed, const uint64_t* seed_offset, const float* sample_scale, int dtype,
+                                   hipStream_t stream) {
     if (am_check("attn_bwd_mfma", mode, B, H, hd, N, nW, res, ws, shift)) return 1;
     MV_CHECK_ARG(passes >= 1 && passes <= 3, "attn_bwd_mfma: passes is a mask of 1 (delta + dQ + dK/dV) and 2 (bias-table gradient)");
     MV_CHECK_ARG(dtype == MVULD_BF16, "attn_bwd_mfma: bf16 storage only");
@@ -1650,6 +1719,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
     MV_CHECK_ARG(attn_drop_p >= 0.f && attn_drop_p < 1.f && (attn_drop_p == 0.f || mode >= 1), "attn_bwd_mfma: attention dropout is a mode 1 / 2 feature, 0 <= p < 1");
     AttnGeom g{mode, B, H, N, nW, res, ws, shift, scale, nullptr, 0, 0, 0, 1.f, nullptr};
     g.yskip = am_yskip_on();
+    g.sscale = mode == 0 ? sample_scale : nullptr;
     am_set_dropout(g, mode, attn_drop_p, drop_seed, seed_offset);
     int64_t ntok = (int64_t)B * nW * N;
     if (mode == 2) { g.mode = 1; g.cu = valid; valid = nullptr; mode = 1; ntok = res; }

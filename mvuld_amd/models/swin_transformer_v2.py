@@ -92,7 +92,8 @@ class _SwinBlockFn(torch.autograd.Function):
         hidden, table16 = blk._cpb_tables(x.device)
         ls = a.logit_scale.data.view(-1)
         geom = ops.AttnGeom(0, B, H, C // H, ws * ws, (res // ws) ** 2, res, ws, shift)
-        att, lse = ops.attn_fwd(geom, qkv, table16, ls)
+        # (rowscale: the block's per-sample DropPath factors -- samples dropped in this block are not computed by the attention kernels)
+        att, lse = ops.attn_fwd(geom, qkv, table16, ls, sample_scale=rowscale)
         proj = ops.gemm_nt(att, ops.weight(a.proj.weight, ad), bias=a.proj.bias.data)
         x1, mean1, rstd1, _, x1q = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x, rowscale=rowscale,
                                                      rows_per_sample=L, emit=ops.fp8_site(blk, "x1", x.device) if fp8 else False)
@@ -157,7 +158,7 @@ class _SwinBlockFn(torch.autograd.Function):
             zbuf = torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
         dtable = zbuf[:T2 * H].view(T2, H)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
-                            ops.grad_of(a.logit_scale).view(-1))
+                            ops.grad_of(a.logit_scale).view(-1), sample_scale=rowscale)
         bst = ops.BIAS_STREAM[0]                  # where attn_bwd left dtable (the weight-gradient stream when one is active)
         if bst is not None:
             hidden.record_stream(bst)

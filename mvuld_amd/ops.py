@@ -891,7 +891,7 @@ def _mfma_attn_ok(g: AttnGeom, dtype):
     return need <= 160 * 1024
 
 
-def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
+def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None, sample_scale=None):
     tokens = qkv.shape[0]
     out = torch.empty((tokens, g.H * g.hd), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((g.B * g.nW * g.H * g.N,), dtype=torch.float32, device=qkv.device)
@@ -901,7 +901,7 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     hip.TIMING.annotate(name, 4.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
     if name == "attn_fwd_mfma":
         call(name, *g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(lse), g.drop_p, g.drop_seed,
-             rng_offset_ptr(), dt(qkv))
+             rng_offset_ptr(), ptr(sample_scale) if USE_DROPPATH_SKIP[0] else None, dt(qkv))
     else:
         if g.drop_p > 0.0:
             raise RuntimeError("attention-probability dropout exists on the matrix-core attention path only (bf16)")
@@ -909,11 +909,14 @@ def attn_fwd(g: AttnGeom, qkv, table16=None, logit_scale=None, valid=None):
     return out, lse
 
 
+# DropPath as a saving: the attention kernels write zeros for the samples whose residual branch is dropped in this block (sample_scale == 0)
+USE_DROPPATH_SKIP = [os.environ.get("MVULD_DROPPATH_SKIP", "1") != "0"]
 BIAS_STREAM = [None]       # stream on which the last attn_bwd left dtable16 (None = the current one)
 
 
-def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None):
+def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None, sample_scale=None):
     dqkv = torch.empty_like(qkv)
+    ss = ptr(sample_scale) if USE_DROPPATH_SKIP[0] else None
     BIAS_STREAM[0] = None
     if _mfma_attn_ok(g, qkv.dtype):
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
@@ -925,11 +928,11 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         if g.mode != 0 or wg is None:
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
             call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed,
-                 rng_offset_ptr(), dt(qkv))
+                 rng_offset_ptr(), ss, dt(qkv))
             return dqkv
         # The bias-table gradient feeds nothing else in backward: dQ / dK / dV stay on this stream, the table pass (and whatever
         # the caller does with dtable16 afterwards: see bias_stream) goes to the weight-gradient stream.
-        call("attn_bwd_mfma", *args, None, 0, 1, 0.0, 0, None, dt(qkv))
+        call("attn_bwd_mfma", *args, None, 0, 1, 0.0, 0, None, ss, dt(qkv))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(qkv.device))
         wg.wait_event(ev)
@@ -937,7 +940,7 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
             t.record_stream(wg)
         with torch.cuda.stream(wg):
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws))
-            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, 0.0, 0, None, dt(qkv))
+            call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4, 2, 0.0, 0, None, ss, dt(qkv))
         BIAS_STREAM[0] = wg
         return dqkv
     hip.TIMING.annotate("attn_bwd_simple", 10.0 * g.N * g.N * g.hd * g.H * g.B * g.nW)

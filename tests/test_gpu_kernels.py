@@ -647,6 +647,40 @@ def test_shifted_window_vertical_mask_split_skip_is_bit_identical(gpu, res, ws, 
     assert bool(torch.isfinite(got[1][2].float()).all())
 
 
+@pytest.mark.parametrize("res,ws,shift,H", [(56, 28, 14, 2), (28, 28, 0, 3), (28, 14, 7, 2), (16, 8, 4, 2)])
+def test_window_attention_skips_droppath_dropped_samples(gpu, res, ws, shift, H):
+    """sample_scale = the block's per-sample DropPath factors (swin_transformer_v2.py:301).  Samples whose factor is 0 are not computed:
+    their `out` / lse rows and dqkv rows are zeros, they add nothing to d(bias table) / d(logit_scale); every other sample's rows are
+    bit-identical to a call without the vector.  (Downstream the dropped samples' branch is multiplied by 0 and their d(out) IS 0, which
+    is what the reference computes the long way; here d(out) of the dropped samples is zeroed for the comparison run.)"""
+    from mvuld_amd import ops
+    B, hd = 5, 32
+    C = H * hd
+    L = res * res
+    T2 = (2 * ws - 1) ** 2
+    qkv = dev(rt(T("sq", (B * L, 3 * C), -2, 2), torch.bfloat16), torch.bfloat16)
+    dout = dev(rt(T("sd", (B * L, C)), torch.bfloat16), torch.bfloat16)
+    table, ls = dev(T("st", (T2, H), 0.0, 16.0)), dev(T("sls", (H,), 1.5, 3.0))
+    scale = torch.tensor([1.25, 0.0, 1.25, 0.0, 1.25], device=gpu)
+    keep = (scale != 0).repeat_interleave(L)
+    g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+
+    def run(ss, do):
+        out, lse = ops.attn_fwd(g, qkv, table, ls, sample_scale=ss)
+        dtab, dls = torch.zeros((T2, H), device=gpu), torch.zeros(H, device=gpu)
+        dqkv = ops.attn_bwd(g, qkv, out, do, lse, table, ls, None, dtab, dls, sample_scale=ss)
+        torch.cuda.synchronize()
+        return out, lse.view(B, -1), dqkv, dtab, dls
+    assert ops.USE_DROPPATH_SKIP[0]
+    full = run(None, dout * keep.view(-1, 1).to(dout.dtype))
+    skip = run(scale, dout)                                  # d(out) of the dropped samples is never read
+    assert torch.equal(skip[0][keep], full[0][keep]) and float(skip[0][~keep].float().abs().max()) == 0.0
+    kb = scale != 0
+    assert torch.equal(skip[1][kb], full[1][kb]) and float(skip[1][~kb].abs().max()) == 0.0
+    assert torch.equal(skip[2][keep], full[2][keep]) and float(skip[2][~keep].float().abs().max()) == 0.0
+    assert rel(skip[3], full[3]) < 1e-5 and rel(skip[4], full[4]) < 1e-5          # sums of float atomics: order not fixed
+
+
 @pytest.mark.parametrize("dtype,impl", [(torch.float32, "simple"), (torch.bfloat16, "simple"), (torch.bfloat16, "auto")])
 @pytest.mark.parametrize("hd,L", [(32, 100), (64, 100), (64, 512)])
 def test_padmask_attention(gpu, dtype, impl, hd, L):

@@ -122,6 +122,35 @@ def test_backward_done_hook_sees_the_deferred_weight_gradients(gpu):
     assert torch.equal(snap["qkv"], qkv.grad)
 
 
+def test_swin_droppath_skip_equals_computing_the_dropped_samples(gpu):
+    """DropPath as a saving (ops.USE_DROPPATH_SKIP): with stochastic depth on, the attention kernels do not compute the samples a block
+    drops.  Same mask stream, skip on / off: the features are identical and every parameter gradient agrees to the rounding of its atomic
+    sums (the dropped samples' branch is multiplied by 0 in the forward and their d(out) is 0 in the backward either way)."""
+    from mvuld_amd import ops
+    from mvuld_amd.models.swin_transformer_v2 import SwinTransformerV2
+    m = SwinTransformerV2(num_classes=2, drop_path_rate=0.6, act_dtype=torch.bfloat16, **SWIN_SMALL)
+    load_synth_into(m)
+    m = m.to(gpu).train()
+    x = _images(4, 448).to(gpu)
+    wv = synth.tensor("swin/dpw", (4, 256)).to(gpu)
+    res = {}
+    try:
+        for skip in (True, False):
+            ops.USE_DROPPATH_SKIP[0] = skip
+            m._dp_seed = 0x1234567
+            for p_ in m.parameters():
+                p_.grad = None
+            f = m.forward_features(x)
+            (f.float() * wv).sum().backward()
+            torch.cuda.synchronize()
+            res[skip] = (f.detach().clone(), {n: p_.grad.clone() for n, p_ in m.named_parameters() if p_.grad is not None})
+    finally:
+        ops.USE_DROPPATH_SKIP[0] = True
+    assert torch.equal(res[True][0], res[False][0])
+    worst = max((rel_l2(res[True][1][n], g_), n) for n, g_ in res[False][1].items() if float(g_.abs().max()) > 0)
+    assert worst[0] < 1e-5, worst
+
+
 ROB_TINY = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
                 max_position_embeddings=130)
 
