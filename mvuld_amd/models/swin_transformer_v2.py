@@ -74,6 +74,9 @@ class _SwinBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, blk, rowscale):
+        # rowscale: None or [2, B] per-sample DropPath factors -- row 0 for the attention branch (:301), row 1 for the FFN branch (:304):
+        # the reference's two drop_path calls draw independent masks
+        rs_a, rs_m = (rowscale[0], rowscale[1]) if rowscale is not None else (None, None)
         a = blk.attn
         B, res, C, H = blk._batch, blk.input_resolution[0], blk.dim, blk.num_heads
         ws, shift = blk.window_size, blk.shift_size
@@ -93,9 +96,9 @@ class _SwinBlockFn(torch.autograd.Function):
         ls = a.logit_scale.data.view(-1)
         geom = ops.AttnGeom(0, B, H, C // H, ws * ws, (res // ws) ** 2, res, ws, shift)
         # (rowscale: the block's per-sample DropPath factors -- samples dropped in this block are not computed by the attention kernels)
-        att, lse = ops.attn_fwd(geom, qkv, table16, ls, sample_scale=rowscale)
+        att, lse = ops.attn_fwd(geom, qkv, table16, ls, sample_scale=rs_a)
         proj = ops.gemm_nt(att, ops.weight(a.proj.weight, ad), bias=a.proj.bias.data)
-        x1, mean1, rstd1, _, x1q = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x, rowscale=rowscale,
+        x1, mean1, rstd1, _, x1q = ops.layernorm_fwd(proj, blk.norm1.weight.data, blk.norm1.bias.data, LN_EPS, residual=x, rowscale=rs_a,
                                                      rows_per_sample=L, emit=ops.fp8_site(blk, "x1", x.device) if fp8 else False)
         # the pre-activation is kept for dGELU only: inference skips that write (and, in fp8, the bf16 copy of the activation too)
         fused_mlp = (not fp8) and ops.mlp_fused_ok(x1, blk.mlp.fc1.weight, training=need_bwd)
@@ -110,7 +113,7 @@ class _SwinBlockFn(torch.autograd.Function):
         else:
             hact = ops.gemm_nt(x1, ops.weight(blk.mlp.fc1.weight, ad), bias=blk.mlp.fc1.bias.data, epi=ops.gelu_epi(hpre), aux=hpre)
             m = ops.gemm_nt(hact, ops.weight(blk.mlp.fc2.weight, ad), bias=blk.mlp.fc2.bias.data)
-        x2, mean2, rstd2, _, x2q = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1, rowscale=rowscale,
+        x2, mean2, rstd2, _, x2q = ops.layernorm_fwd(m, blk.norm2.weight.data, blk.norm2.bias.data, LN_EPS, residual=x1, rowscale=rs_m,
                                                      rows_per_sample=L,
                                                      emit=ops.fp8_site(blk, "x2", x.device) if (fp8 and getattr(blk, "_q8_next", False)) else False)
         ops.fp8_put(x2, x2q)                # the next block's QKV product takes it
@@ -129,13 +132,14 @@ class _SwinBlockFn(torch.autograd.Function):
     def _backward(ctx, g):
         x, qkv, att, lse, proj, mean1, rstd1, x1, hpre, hact, m, mean2, rstd2, table16, hidden, rowscale = ctx.saved_tensors
         blk, geom = ctx.blk, ctx.geom
+        rs_a, rs_m = (rowscale[0], rowscale[1]) if rowscale is not None else (None, None)
         a = blk.attn
         ad = x.dtype
         L = blk.input_resolution[0] ** 2
         C, H = blk.dim, blk.num_heads
         g = g.contiguous()
         # ---- FFN branch: x2 = x1 + rs * LN(m)
-        dm = ops.layernorm_bwd(g, m, blk.norm2.weight, blk.norm2.bias, mean2, rstd2, rowscale, L)
+        dm = ops.layernorm_bwd(g, m, blk.norm2.weight, blk.norm2.bias, mean2, rstd2, rs_m, L)
         ops.linear_wgrad(dm, hact, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
         if hpre is None:        # fused MLP: d(pre-activation) and the block-input gradient in one kernel (pre-activation recomputed)
             dhpre, g1 = ops.mlp_fused_bwd(x1, dm, g, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight)
@@ -145,7 +149,7 @@ class _SwinBlockFn(torch.autograd.Function):
             ops.linear_wgrad(dhpre, x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
             g1 = ops.gemm_nt(dhpre, ops.weight_t(blk.mlp.fc1.weight, ad), epi=hip.EPI_ADD_AUX, aux=g)
         # ---- attention branch: x1 = x + rs * LN(proj)
-        dproj = ops.layernorm_bwd(g1, proj, blk.norm1.weight, blk.norm1.bias, mean1, rstd1, rowscale, L)
+        dproj = ops.layernorm_bwd(g1, proj, blk.norm1.weight, blk.norm1.bias, mean1, rstd1, rs_a, L)
         ops.linear_wgrad(dproj, att, a.proj.weight, a.proj.bias)
         datt = ops.gemm_nt(dproj, ops.weight_t(a.proj.weight, ad))
         T2 = table16.shape[0]
@@ -158,7 +162,7 @@ class _SwinBlockFn(torch.autograd.Function):
             zbuf = torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
         dtable = zbuf[:T2 * H].view(T2, H)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
-                            ops.grad_of(a.logit_scale).view(-1), sample_scale=rowscale)
+                            ops.grad_of(a.logit_scale).view(-1), sample_scale=rs_a)
         bst = ops.BIAS_STREAM[0]                  # where attn_bwd left dtable (the weight-gradient stream when one is active)
         if bst is not None:
             hidden.record_stream(bst)
@@ -456,8 +460,9 @@ class SwinTransformerV2(nn.Module):
         return {"cpb_mlp", "logit_scale", 'relative_position_bias_table'}
 
     def _droppath_scales(self, B, device):
-        """[n_blocks, B] per-sample keep/(1-p) factors (timm DropPath semantics), drawn on the device by one kernel launch."""
-        rates = [blk.drop_path_rate for layer in self.layers for blk in layer.blocks]
+        """[2 * n_blocks, B] per-sample keep/(1-p) factors (timm DropPath semantics: a fresh mask per call, and a block calls it twice --
+        rows 2k / 2k + 1 belong to block k's attention / FFN branch), drawn on the device by one kernel launch."""
+        rates = [blk.drop_path_rate for layer in self.layers for blk in layer.blocks for _ in range(2)]
         if not self.training or max(rates) <= 0.0:
             return None
         if self._dp_rates is None or self._dp_rates.device != device:
@@ -481,7 +486,7 @@ class SwinTransformerV2(nn.Module):
         for layer in self.layers:
             for i, blk in enumerate(layer.blocks):
                 blk._q8_next = i + 1 < len(layer.blocks)
-                rs = scales[k] if (scales is not None and blk.drop_path_rate > 0) else None
+                rs = scales[2 * k:2 * k + 2] if (scales is not None and blk.drop_path_rate > 0) else None
                 t = blk(t, B, rs)
                 k += 1
             if layer.downsample is not None:

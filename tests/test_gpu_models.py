@@ -149,6 +149,16 @@ def test_swin_droppath_skip_equals_computing_the_dropped_samples(gpu):
     assert torch.equal(res[True][0], res[False][0])
     worst = max((rel_l2(res[True][1][n], g_), n) for n, g_ in res[False][1].items() if float(g_.abs().max()) > 0)
     assert worst[0] < 1e-5, worst
+    # the masks themselves: timm DropPath draws a fresh mask per call and a block calls it twice (attention branch :301, FFN branch :304):
+    # two rows per block, each value 0 or 1 / (1 - p_k), the two rows of a block independent
+    sc = m._droppath_scales(64, gpu).cpu()
+    rates = [b.drop_path_rate for l in m.layers for b in l.blocks]
+    assert sc.shape == (2 * len(rates), 64)
+    for k, p_ in enumerate(rates):
+        for r in sc[2 * k:2 * k + 2]:
+            assert bool(((r == 0) | ((r - 1.0 / (1.0 - p_)).abs() < 1e-5)).all())
+    late = sc[2 * (len(rates) - 1):]                      # p = 0.6: 64 draws per row
+    assert 0.3 < float((late == 0).float().mean()) < 0.9 and not torch.equal(late[0], late[1])
 
 
 ROB_TINY = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
