@@ -549,6 +549,8 @@ class wgrad_group:
             try:
                 if exc[0] is None:
                     wgrad_group_flush()
+                else:
+                    del _LN_PENDING[:]        # a backward that raised: its deferred LayerNorm partials must not reach a later step's gradients
             finally:
                 _WGRAD_PENDING[0] = None
         return False
