@@ -1160,6 +1160,121 @@ extern "C" int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, in
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ fp32 operands, split in registers
+// The head's fp32 tail (GAT / Rs_GCN / classifier products, M ~ 3200 nodes or 32 x [100 x 100]) runs on the bf16 matrix cores as
+//   a . b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo,   x_hi = bf16(x), x_lo = bf16(x - x_hi)   (error ~2^-16, fp32 accumulation).
+// Rounds 1-2 materialised [hi | lo | hi] / [hi | hi | lo] copies of both operands (two split3_k launches per product, 224 per step)
+// and ran a 3K-deep bf16 product; here the split happens on the way from the global loads to LDS: one launch per product, no copies.
+// 64 x 64 tile, 4 waves (2 x 2) x (32 x 32), 32-deep steps, register-staged double buffering; every epilogue of mvuld_gemm_nt through
+// epilogue_store (these products are small: the element-wise store is not what bounds them); batched; splitk == 1.
+#define F3_LD 40                                    // bf16 elements per LDS row (32 + 8: 80-byte rows)
+__global__ __launch_bounds__(256) void gemm_nt_f32x3_k(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16 sm[2][4][64 * F3_LD];       // [stage][A_hi, A_lo, B_hi, B_lo]
+    const int b = blockIdx.z;
+    const float* A = (const float*)g.A + (int64_t)b * g.sA;
+    const float* B = (const float*)g.B + (int64_t)b * g.sB;
+    float* C = (float*)g.C + (int64_t)b * g.sC;
+    float* aux = g.aux ? (float*)g.aux + (int64_t)b * g.sAux : nullptr;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fg = lane >> 4;
+    // staging map: thread t loads row t >> 2, k offsets (t & 3) * 8 .. + 7 of both operands (two float4 each)
+    const int lr = tid >> 2, lk = (tid & 3) * 8;
+    const int ra = min(m0 + lr, g.M - 1), rb = min(n0 + lr, g.N - 1);
+    const float* pa = A + (int64_t)ra * g.lda;
+    const float* pb = B + (int64_t)rb * g.ldb;
+    const bool vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+                     (g.sA % 4 == 0) && (g.sB % 4 == 0);
+    float xa[8], xb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + lk + 4 * h;
+            if (vec && k + 3 < g.K) {
+                const float4 va = *(const float4*)(pa + k), vb = *(const float4*)(pb + k);
+                xa[4 * h] = va.x; xa[4 * h + 1] = va.y; xa[4 * h + 2] = va.z; xa[4 * h + 3] = va.w;
+                xb[4 * h] = vb.x; xb[4 * h + 1] = vb.y; xb[4 * h + 2] = vb.z; xb[4 * h + 3] = vb.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = min(k + e, g.K - 1);
+                    const float va = pa[kk], vb = pb[kk];
+                    xa[4 * h + e] = k + e < g.K ? va : 0.f;
+                    xb[4 * h + e] = k + e < g.K ? vb : 0.f;
+                }
+            }
+        }
+    };
+    auto stage = [&](int st) {
+        bf16x8 ah, al, bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ah.v[e] = (bf16)xa[e]; al.v[e] = (bf16)(xa[e] - (float)ah.v[e]);
+            bh.v[e] = (bf16)xb[e]; bl.v[e] = (bf16)(xb[e] - (float)bh.v[e]);
+        }
+        const int o = lr * F3_LD + lk;
+        *(bf16x8*)(&sm[st][0][o]) = ah; *(bf16x8*)(&sm[st][1][o]) = al;
+        *(bf16x8*)(&sm[st][2][o]) = bh; *(bf16x8*)(&sm[st][3][o]) = bl;
+    };
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nk = (g.K + 31) / 32;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        const int st = c & 1;
+        if (c + 1 < nk) fetch((c + 1) * 32);            // next step's operands fly under this step's MFMAs
+        bf16x8_t fah[2], fal[2], fbh[2], fbl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oa = (wr * 32 + i * 16 + fr) * F3_LD + fg * 8, ob = (wc * 32 + i * 16 + fr) * F3_LD + fg * 8;
+            fah[i] = *(const bf16x8_t*)(&sm[st][0][oa]); fal[i] = *(const bf16x8_t*)(&sm[st][1][oa]);
+            fbh[i] = *(const bf16x8_t*)(&sm[st][2][ob]); fbl[i] = *(const bf16x8_t*)(&sm[st][3][ob]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+            }
+        if (c + 1 < nk) stage(st ^ 1);                   // the other stage was last read two barriers ago
+        __syncthreads();
+    }
+    // acc[i][j][r] = C[m0 + wr*32 + i*16 + 4*fg + r][n0 + wc*32 + j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 32 + i * 16 + 4 * fg + r, col = n0 + wc * 32 + j * 16 + fr;
+                if (row < g.M && col < g.N) epilogue_store<float>(g, C, aux, row, col, acc[i][j][r]);
+            }
+}
+
+// C[b] (fp32) = epilogue(alpha * A[b] . B[b]^T + bias) for fp32 operands at near-fp32 accuracy on the bf16 matrix cores
+extern "C" int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                                   int64_t strideC, int M, int N, int K, int batch, const float* bias, int epilogue, float* aux, int64_t ldaux,
+                                   int64_t strideAux, float alpha, int out_mode, hipStream_t stream) {
+    MV_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "gemm_nt_f32x3: bad args");
+    MV_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_MUL_AUX && !(epi_reads_aux(epilogue) && !aux), "gemm_nt_f32x3: epilogue %d", epilogue);
+    MV_CHECK_ARG(out_mode == OUT_STORE || out_mode == OUT_ACCUM || (out_mode == OUT_ATOMIC && epilogue <= EPI_BIAS), "gemm_nt_f32x3: out_mode %d", out_mode);
+    MV_CHECK_ARG((int64_t)cdiv(M, 64) < 65536 && batch < 65536, "gemm_nt_f32x3: grid");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.splitk = 1; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.sAux = strideAux;
+    g.alpha = alpha; g.epi = epilogue; g.out_mode = out_mode; g.scale_a = nullptr; g.scale_b = nullptr;
+    hipLaunchKernelGGL(gemm_nt_f32x3_k, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)batch), dim3(256), 0, stream, g);
+    MV_LAUNCH_CHECK("gemm_nt_f32x3");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static std::atomic<int> g_k256{-1};     // minimum K for the 256 x 256 ring kernel (0 = never); -1 = read MVULD_GEMM_256 on first use
 

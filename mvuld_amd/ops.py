@@ -18,6 +18,7 @@ WEIGHT_EPOCH = [0]
 FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU kernel
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
 USE_SPLIT3 = [False]                 # fp32 GEMMs (the head's fp32 tail) as 3-term bf16 splits on the matrix cores
+SPLIT3_IN_REGISTERS = [os.environ.get("MVULD_SPLIT3_FUSED", "1") != "0"]      # ... split inside the GEMM kernel (0: two split launches + a 3K-deep product)
 USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
 USE_TN_SLABS = [os.environ.get("MVULD_TN_SLABS", "1") != "0"]     # ... whose split contraction (2..8 ways) goes through a slab workspace, not atomics
 
@@ -148,6 +149,14 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
         raise TypeError("gemm_nt: bias must be fp32")
     if (a.dtype == torch.float32 and b.dtype == torch.float32 and USE_SPLIT3[0] and not FORCE_SIMPLE_GEMM[0] and M >= 64 and N >= 64
             and (aux is None or aux.dtype == out.dtype)):
+        if (SPLIT3_IN_REGISTERS[0] and splitk == 1 and out.dtype == torch.float32
+                and (out_mode != hip.OUT_ATOMIC or epi <= hip.EPI_BIAS)):
+            # ... split on the way from memory to LDS: one launch, no operand copies (mvuld_gemm_nt_f32x3)
+            if hip.TIMING.enabled:
+                hip.TIMING.annotate("gemm_nt_mfma_bf16(split3 fp32)", 6.0 * M * N * K * batch)
+            call("gemm_nt_f32x3", ptr(a), lda, sa, ptr(b), ldb, sb, ptr(out), ldc, sc, M, N, K, batch, ptr(bias), epi, ptr(aux), ldaux or 0, saux,
+                 float(alpha), out_mode)
+            return out
         # near-fp32 product on the bf16 matrix cores: both operands split into hi/lo bf16 parts concatenated along K
         Kp = (K + 7) // 8 * 8
         ra, rb = M * batch, N * batch

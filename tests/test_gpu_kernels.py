@@ -63,6 +63,44 @@ def test_gemm_nt_bias_epilogues(gpu, dtype, M, N, K):
     assert out32.dtype == torch.float32 and rel(out32, ref) < (2e-4 if dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(3200, 512, 512, 1), (100, 512, 100, 32), (100, 100, 512, 32), (70, 65, 36, 1), (130, 64, 33, 3), (64, 200, 7, 1)])
+def test_gemm_nt_fp32_split_in_registers(gpu, M, N, K, batch):
+    """mvuld_gemm_nt_f32x3: fp32 operands split into bf16 hi / lo parts on the way to LDS, three products per 32-deep step (the head's
+    fp32 tail in the bf16 activation mode; rounds 1-2 ran two split launches and a 3K-deep bf16 product).  Against the fp64 product
+    (error of the scheme ~2^-16 per term) and against the three-launch path on the same operands; bias, ELU, residual-join and
+    accumulate forms; batched operands with their own strides; K not a multiple of 4 / 32, ragged M / N."""
+    from mvuld_amd import ops, hip
+    g_ = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(batch, M, K, generator=g_)
+    b = torch.randn(batch, N, K, generator=g_)
+    bias, auxv = torch.randn(N, generator=g_), torch.randn(batch, M, N, generator=g_)
+    ref = (a.double() @ b.double().transpose(1, 2))
+    A, B_, Bi, AX = a.to(gpu), b.to(gpu), bias.to(gpu), auxv.to(gpu)
+    kw = dict(M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch=batch, sa=M * K, sb=N * K, sc=M * N)
+    ops.USE_SPLIT3[0] = True
+    try:
+        assert ops.SPLIT3_IN_REGISTERS[0]
+        out = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), **kw)
+        assert rel(out, ref.float()) < 3e-5, rel(out, ref.float())
+        ops.SPLIT3_IN_REGISTERS[0] = False
+        try:
+            old = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), **kw)
+        finally:
+            ops.SPLIT3_IN_REGISTERS[0] = True
+        assert rel(out, old) < 2e-6, rel(out, old)
+        out = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), bias=Bi, **kw)
+        assert rel(out, (ref + bias.double()).float()) < 3e-5
+        out = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), bias=Bi, epi=hip.EPI_ELU, **kw)
+        assert rel(out, F.elu((ref + bias.double()).float())) < 3e-5
+        out = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), epi=hip.EPI_ADD_AUX, aux=AX, ldaux=N, saux=M * N, **kw)
+        assert rel(out, (ref + auxv.double()).float()) < 3e-5
+        acc = AX.clone()
+        ops.gemm_nt(A, B_, out=acc, out_mode=hip.OUT_ACCUM, alpha=0.5, **kw)
+        assert rel(acc, (0.5 * ref + auxv.double()).float()) < 3e-5
+    finally:
+        ops.USE_SPLIT3[0] = False
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_splitk_atomic_and_batched(gpu, dtype):
     from mvuld_amd import ops, hip
