@@ -55,11 +55,13 @@ int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, in
 /* The same product for fp32 operands and an fp32 result at near-fp32 accuracy on the bf16 matrix cores: every operand element is split
  * into hi = bf16(x) and lo = bf16(x - hi) ON THE WAY from memory to LDS and the kernel accumulates a_hi b_hi + a_lo b_hi + a_hi b_lo in
  * fp32 (error ~2^-16).  One launch, no operand copies (rounds 1-2: mvuld_split_bf16x3 on both operands + a 3K-deep bf16 product).
- * Every epilogue and out_mode of mvuld_gemm_nt (atomic: NONE / BIAS only), batched, no contraction split.  The head's fp32 tail:
+ * Every epilogue and out_mode of mvuld_gemm_nt (atomic: NONE / BIAS only), batched.  trans_a / trans_b: that operand is stored [K, M] /
+ * [K, N] (lda / ldb = its row stride) -- products like R^T dY or the weight gradient dY^T X without a transpose pass; splitk > 1 splits the
+ * contraction over workgroups that add into C with atomics (out_mode ATOMIC only).  The head's fp32 tail:
  * GATConv.fc, GraphModel.py:153-209, Rs_GCN.py:57-70 in the bf16 activation mode. */
 int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                         int64_t strideC, int M, int N, int K, int batch, const float* bias, int epilogue, float* aux, int64_t ldaux,
-                        int64_t strideAux, float alpha, int out_mode, mvuld_stream_t stream);
+                        int64_t strideAux, float alpha, int out_mode, int trans_a, int trans_b, int splitk, mvuld_stream_t stream);
 
 /* Opt-in for the experimental 256 x 256-tile, 4-stage LDS-DMA ring variant of mvuld_gemm_nt: products with K >= min_k
  * (K % 32 == 0, >= 128 tiles, plain store) take it; 0 (default) = never.  No stream argument: host-side setting. */

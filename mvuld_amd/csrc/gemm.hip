@@ -1165,87 +1165,145 @@ extern "C" int mvuld_gemm_nt_fp8(const void* A8, int64_t lda, const void* B8, in
 //   a . b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo,   x_hi = bf16(x), x_lo = bf16(x - x_hi)   (error ~2^-16, fp32 accumulation).
 // Rounds 1-2 materialised [hi | lo | hi] / [hi | hi | lo] copies of both operands (two split3_k launches per product, 224 per step)
 // and ran a 3K-deep bf16 product; here the split happens on the way from the global loads to LDS: one launch per product, no copies.
-// 64 x 64 tile, 4 waves (2 x 2) x (32 x 32), 32-deep steps, register-staged double buffering; every epilogue of mvuld_gemm_nt through
+// 64 x 64 tile, 4 waves (2 x 2) x (32 x 32), 64-deep steps, register-staged double buffering; every epilogue of mvuld_gemm_nt through
 // epilogue_store (these products are small: the element-wise store is not what bounds them); batched; splitk == 1.
-#define F3_LD 40                                    // bf16 elements per LDS row (32 + 8: 80-byte rows)
+#define F3_KS 64                                    // contraction elements per step (two 32-wide chunks: these products are latency-bound, not MFMA-bound)
+#define F3_LD (F3_KS + 8)                           // bf16 elements per LDS row (144-byte rows)
+#define F3_LDS_BYTES (2 * 4 * 64 * F3_LD * 2)       // two stages x {A_hi, A_lo, B_hi, B_lo}
+// one operand's 64 x 32 piece of a k-step: 8 floats per thread.  Row-major operand ([rows, K], ld): thread -> row t >> 2, k (t & 3) * 8 .. + 7.
+// Transposed operand ([K, rows], ld): thread -> k t >> 3, rows (t & 7) * 8 .. + 7 (contiguous in memory).  Out-of-range elements are zeros.
+template <bool trans>
+__device__ __forceinline__ void f3_fetch(const float* __restrict__ P, int64_t ld, bool vec, int r0, int rows, int k0, int K, int tid, float (&x)[8]) {
+    if constexpr (!trans) {
+        const int lr = tid >> 2, lk = (tid & 3) * 8;
+        const float* p = P + (int64_t)min(r0 + lr, rows - 1) * ld;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + lk + 4 * h;
+            if (vec && k + 3 < K) {
+                const float4 v = *(const float4*)(p + k);
+                x[4 * h] = v.x; x[4 * h + 1] = v.y; x[4 * h + 2] = v.z; x[4 * h + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = p[min(k + e, K - 1)]; x[4 * h + e] = k + e < K ? v : 0.f; }
+            }
+        }
+    } else {
+        const int kk = k0 + (tid >> 3), seg = r0 + (tid & 7) * 8;
+        const float* p = P + (int64_t)min(kk, K - 1) * ld;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = seg + 4 * h;
+            if (vec && kk < K && r + 3 < rows) {
+                const float4 v = *(const float4*)(p + r);
+                x[4 * h] = v.x; x[4 * h + 1] = v.y; x[4 * h + 2] = v.z; x[4 * h + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = p[min(r + e, rows - 1)]; x[4 * h + e] = (kk < K && r + e < rows) ? v : 0.f; }
+            }
+        }
+    }
+}
+template <bool trans>
+__device__ __forceinline__ void f3_stage(bf16* __restrict__ hi, bf16* __restrict__ lo, int tid, const float (&x)[8]) {      // (hi / lo already offset to the chunk's column)
+    bf16x8 h8, l8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h8.v[e] = (bf16)x[e]; l8.v[e] = (bf16)(x[e] - (float)h8.v[e]); }
+    if constexpr (!trans) {
+        const int o = (tid >> 2) * F3_LD + (tid & 3) * 8;
+        *(bf16x8*)(hi + o) = h8; *(bf16x8*)(lo + o) = l8;
+    } else {                                             // kept as it is stored, [k][row]: the fragments come out through transposed reads
+        const int o = (tid >> 3) * F3_LD + (tid & 7) * 8;
+        *(bf16x8*)(hi + o) = h8; *(bf16x8*)(lo + o) = l8;
+    }
+}
+// MFMA fragment of 16 rows r0 .. r0+15 x 32 k (chunk kc) of one plane: lane (fr, fg) holds k = 8 fg .. 8 fg + 7 of row r0 + fr.
+// Row-major plane [row][F3_LD]: one 16-byte read.  Transposed plane [k][F3_LD] (chunk kc = rows 32 kc .. of it): two ds_read_b64_tr_b16 --
+// lane 4q + p of a 16-lane group addresses k-row 8 fg (+ 4) + q, tile rows 4p .. 4p + 3, and receives tile row (lane & 15) of the four k-rows.
+template <bool trans>
+__device__ __forceinline__ bf16x8_t f3_frag(const bf16* __restrict__ plane, int r0, int kc, int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    if constexpr (!trans) {
+        return *(const bf16x8_t*)(plane + (r0 + fr) * F3_LD + 32 * kc + fg * 8);
+    } else {
+        typedef bf16 __attribute__((ext_vector_type(4))) f3_bf16x4_t;
+        typedef __attribute__((address_space(3))) f3_bf16x4_t* lds_p4;
+        const int q = fr >> 2, pp = fr & 3;
+        const bf16* a0 = plane + (32 * kc + 8 * fg + q) * F3_LD + r0 + 4 * pp;
+        const f3_bf16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)a0);
+        const f3_bf16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(a0 + 4 * F3_LD));
+        return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+template <bool ta, bool tb>
 __global__ __launch_bounds__(256) void gemm_nt_f32x3_k(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) bf16 sm[2][4][64 * F3_LD];       // [stage][A_hi, A_lo, B_hi, B_lo]
-    const int b = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) char f3_smem[];
+    bf16 (*sm)[4][64 * F3_LD] = (bf16 (*)[4][64 * F3_LD])f3_smem;            // [stage][A_hi, A_lo, B_hi, B_lo][64 rows][F3_LD]
+    constexpr int NC = F3_KS / 32;
+    const int b = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
     const float* A = (const float*)g.A + (int64_t)b * g.sA;
     const float* B = (const float*)g.B + (int64_t)b * g.sB;
     float* C = (float*)g.C + (int64_t)b * g.sC;
     float* aux = g.aux ? (float*)g.aux + (int64_t)b * g.sAux : nullptr;
+    if (ks > 0) g.bias = nullptr;                        // (contraction splits add into C with atomics: the bias once)
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, fg = lane >> 4;
-    // staging map: thread t loads row t >> 2, k offsets (t & 3) * 8 .. + 7 of both operands (two float4 each)
-    const int lr = tid >> 2, lk = (tid & 3) * 8;
-    const int ra = min(m0 + lr, g.M - 1), rb = min(n0 + lr, g.N - 1);
-    const float* pa = A + (int64_t)ra * g.lda;
-    const float* pb = B + (int64_t)rb * g.ldb;
-    const bool vec = (g.K % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
-                     (g.sA % 4 == 0) && (g.sB % 4 == 0);
-    float xa[8], xb[8];
+    // 16-byte loads: along k for a row-major operand (K % 4), along the rows for a transposed one (M or N % 4)
+    const bool veca = (g.lda % 4 == 0) && (g.sA % 4 == 0) && ((((uintptr_t)g.A) & 15) == 0) && ((ta ? g.M : g.K) % 4 == 0);
+    const bool vecb = (g.ldb % 4 == 0) && (g.sB % 4 == 0) && ((((uintptr_t)g.B) & 15) == 0) && ((tb ? g.N : g.K) % 4 == 0);
+    (void)g.ta; (void)g.tb;
+    float xa[NC][8], xb[NC][8];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = k0 + lk + 4 * h;
-            if (vec && k + 3 < g.K) {
-                const float4 va = *(const float4*)(pa + k), vb = *(const float4*)(pb + k);
-                xa[4 * h] = va.x; xa[4 * h + 1] = va.y; xa[4 * h + 2] = va.z; xa[4 * h + 3] = va.w;
-                xb[4 * h] = vb.x; xb[4 * h + 1] = vb.y; xb[4 * h + 2] = vb.z; xb[4 * h + 3] = vb.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kk = min(k + e, g.K - 1);
-                    const float va = pa[kk], vb = pb[kk];
-                    xa[4 * h + e] = k + e < g.K ? va : 0.f;
-                    xb[4 * h + e] = k + e < g.K ? vb : 0.f;
-                }
-            }
+        for (int j = 0; j < NC; ++j) {
+            f3_fetch<ta>(A, g.lda, veca, m0, g.M, k0 + 32 * j, g.K, tid, xa[j]);
+            f3_fetch<tb>(B, g.ldb, vecb, n0, g.N, k0 + 32 * j, g.K, tid, xb[j]);
         }
     };
     auto stage = [&](int st) {
-        bf16x8 ah, al, bh, bl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            ah.v[e] = (bf16)xa[e]; al.v[e] = (bf16)(xa[e] - (float)ah.v[e]);
-            bh.v[e] = (bf16)xb[e]; bl.v[e] = (bf16)(xb[e] - (float)bh.v[e]);
+        for (int j = 0; j < NC; ++j) {               // chunk j: columns 32 j .. of a row-major plane, rows 32 j .. of a transposed one
+            f3_stage<ta>(sm[st][0] + (ta ? 32 * j * F3_LD : 32 * j), sm[st][1] + (ta ? 32 * j * F3_LD : 32 * j), tid, xa[j]);
+            f3_stage<tb>(sm[st][2] + (tb ? 32 * j * F3_LD : 32 * j), sm[st][3] + (tb ? 32 * j * F3_LD : 32 * j), tid, xb[j]);
         }
-        const int o = lr * F3_LD + lk;
-        *(bf16x8*)(&sm[st][0][o]) = ah; *(bf16x8*)(&sm[st][1][o]) = al;
-        *(bf16x8*)(&sm[st][2][o]) = bh; *(bf16x8*)(&sm[st][3][o]) = bl;
     };
     f32x4_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int nk = (g.K + 31) / 32;
-    fetch(0);
-    stage(0);
+    const int nk_all = (g.K + F3_KS - 1) / F3_KS, per = (nk_all + g.splitk - 1) / g.splitk;
+    const int c0 = ks * per, c1 = min(nk_all, c0 + per);
+    if (c0 < c1) {
+        fetch(c0 * F3_KS);
+        stage(0);
+    }
     __syncthreads();
-    for (int c = 0; c < nk; ++c) {
-        const int st = c & 1;
-        if (c + 1 < nk) fetch((c + 1) * 32);            // next step's operands fly under this step's MFMAs
-        bf16x8_t fah[2], fal[2], fbh[2], fbl[2];
+    for (int c = c0; c < c1; ++c) {
+        const int st = (c - c0) & 1;
+        if (c + 1 < c1) fetch((c + 1) * F3_KS);          // next step's operands fly under this step's MFMAs
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int oa = (wr * 32 + i * 16 + fr) * F3_LD + fg * 8, ob = (wc * 32 + i * 16 + fr) * F3_LD + fg * 8;
-            fah[i] = *(const bf16x8_t*)(&sm[st][0][oa]); fal[i] = *(const bf16x8_t*)(&sm[st][1][oa]);
-            fbh[i] = *(const bf16x8_t*)(&sm[st][2][ob]); fbl[i] = *(const bf16x8_t*)(&sm[st][3][ob]);
-        }
+        for (int kc = 0; kc < NC; ++kc) {
+            bf16x8_t fah[2], fal[2], fbh[2], fbl[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                fah[i] = f3_frag<ta>(sm[st][0], wr * 32 + i * 16, kc, lane); fal[i] = f3_frag<ta>(sm[st][1], wr * 32 + i * 16, kc, lane);
+                fbh[i] = f3_frag<tb>(sm[st][2], wc * 32 + i * 16, kc, lane); fbl[i] = f3_frag<tb>(sm[st][3], wc * 32 + i * 16, kc, lane);
             }
-        if (c + 1 < nk) stage(st ^ 1);                   // the other stage was last read two barriers ago
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (c + 1 < c1) stage(st ^ 1);                   // the other stage was last read two barriers ago
         __syncthreads();
     }
+    if (c0 >= c1) return;                                // (a split past the end of the contraction)
     // acc[i][j][r] = C[m0 + wr*32 + i*16 + 4*fg + r][n0 + wc*32 + j*16 + fr]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1258,19 +1316,35 @@ __global__ __launch_bounds__(256) void gemm_nt_f32x3_k(GemmArgs g) {
             }
 }
 
-// C[b] (fp32) = epilogue(alpha * A[b] . B[b]^T + bias) for fp32 operands at near-fp32 accuracy on the bf16 matrix cores
+// C[b] (fp32) = epilogue(alpha * op(A[b]) . op(B[b])^T + bias) for fp32 operands at near-fp32 accuracy on the bf16 matrix cores.
+// trans_a / trans_b: the operand is stored [K, M] / [K, N] (the "TN" and "NN" forms of a product without a transpose pass: Rs_GCN's R^T dY,
+// dR ph, and every weight gradient dY^T X of the head); splitk > 1: contraction splits adding into C with atomics (out_mode ATOMIC).
 extern "C" int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                                    int64_t strideC, int M, int N, int K, int batch, const float* bias, int epilogue, float* aux, int64_t ldaux,
-                                   int64_t strideAux, float alpha, int out_mode, hipStream_t stream) {
-    MV_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "gemm_nt_f32x3: bad args");
+                                   int64_t strideAux, float alpha, int out_mode, int trans_a, int trans_b, int splitk, hipStream_t stream) {
+    MV_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1, "gemm_nt_f32x3: bad args");
     MV_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_MUL_AUX && !(epi_reads_aux(epilogue) && !aux), "gemm_nt_f32x3: epilogue %d", epilogue);
     MV_CHECK_ARG(out_mode == OUT_STORE || out_mode == OUT_ACCUM || (out_mode == OUT_ATOMIC && epilogue <= EPI_BIAS), "gemm_nt_f32x3: out_mode %d", out_mode);
-    MV_CHECK_ARG((int64_t)cdiv(M, 64) < 65536 && batch < 65536, "gemm_nt_f32x3: grid");
+    MV_CHECK_ARG(splitk == 1 || out_mode == OUT_ATOMIC, "gemm_nt_f32x3: a split contraction adds into C with atomics (out_mode ATOMIC)");
+    MV_CHECK_ARG((int64_t)cdiv(M, 64) < 65536 && (int64_t)batch * splitk < 65536, "gemm_nt_f32x3: grid");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
-    g.M = M; g.N = N; g.K = K; g.batch = batch; g.splitk = 1; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.sAux = strideAux;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.splitk = splitk; g.bias = bias; g.aux = aux; g.ldaux = ldaux; g.sAux = strideAux;
     g.alpha = alpha; g.epi = epilogue; g.out_mode = out_mode; g.scale_a = nullptr; g.scale_b = nullptr;
-    hipLaunchKernelGGL(gemm_nt_f32x3_k, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)batch), dim3(256), 0, stream, g);
+    g.ta = trans_a ? 1 : 0; g.tb = trans_b ? 1 : 0;
+    const dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), (unsigned)(batch * splitk));
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_f32x3_k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_f32x3_k<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_f32x3_k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_f32x3_k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    if (g.ta && g.tb) hipLaunchKernelGGL((gemm_nt_f32x3_k<true, true>), grid, dim3(256), F3_LDS_BYTES, stream, g);
+    else if (g.ta) hipLaunchKernelGGL((gemm_nt_f32x3_k<true, false>), grid, dim3(256), F3_LDS_BYTES, stream, g);
+    else if (g.tb) hipLaunchKernelGGL((gemm_nt_f32x3_k<false, true>), grid, dim3(256), F3_LDS_BYTES, stream, g);
+    else hipLaunchKernelGGL((gemm_nt_f32x3_k<false, false>), grid, dim3(256), F3_LDS_BYTES, stream, g);
     MV_LAUNCH_CHECK("gemm_nt_f32x3");
     return 0;
 }

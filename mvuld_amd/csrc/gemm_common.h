@@ -22,6 +22,8 @@ struct GemmArgs {
     // fp8 GELU epilogue: also (or, with C == nullptr, only) emit the activation as e4m3 under the scale at q_scale[0], and fold
     // max|value| into q_amax[0] (atomicMax on the bit pattern of a non-negative float) for the next step's scale
     void* q_out = nullptr; int64_t ldq = 0; const float* q_scale = nullptr; unsigned* q_amax = nullptr;
+    // gemm_nt_f32x3_k only: operand stored transposed -- A as [K, M] (element (m, k) at A[k * lda + m]), B as [K, N]
+    int ta = 0, tb = 0;
 };
 
 typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;

@@ -29,9 +29,13 @@ class _RsGCNFn(torch.autograd.Function):
         gv = ops.gemm_nt(v, ops.weight(mod.g.weight, ad).view(Di, D), bias=mod.g.bias.data)
         # R = theta^T phi / N   per graph: [N, N]
         R = ops.gemm_nt(th, ph, M=N, N=N, K=Di, lda=Di, ldb=Di, batch=B, sa=N * Di, sb=N * Di, alpha=1.0 / N)
-        gvT = ops.transpose(gv, R=N, C=Di, batch=B)                       # [B, Di, N]
         y = torch.empty((B * N, Di), dtype=ad, device=v.device)
-        ops.gemm_nt(R, gvT, out=y, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di)
+        if ops.SPLIT3_TRANS[0] and ops.f32x3_ok(ad, N, Di):
+            # y = R gv with gv read as it is stored ([N, Di] = the product's [K, N] operand): no transpose pass
+            ops.gemm_nt(R, gv, out=y, M=N, N=Di, K=N, lda=N, ldb=Di, ldc=Di, batch=B, sa=N * N, sb=N * Di, sc=N * Di, tb=True)
+        else:
+            gvT = ops.transpose(gv, R=N, C=Di, batch=B)                   # [B, Di, N]
+            ops.gemm_nt(R, gvT, out=y, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di)
         conv, bn = mod.W[0], mod.W[1]
         wy = ops.gemm_nt(y, ops.weight(conv.weight, ad).view(D, Di), bias=conv.bias.data)
         training = mod.training
@@ -60,18 +64,25 @@ class _RsGCNFn(torch.autograd.Function):
         dy = ops.gemm_nt(dwy, ops.weight_t(conv.weight, ad))                                         # [B*N, Di]
         # y = R gv
         dR = ops.gemm_nt(dy, gv, M=N, N=N, K=Di, lda=Di, ldb=Di, batch=B, sa=N * Di, sb=N * Di)     # [B,N,N]
-        RT = ops.transpose(R, R=N, C=N, batch=B)
-        dyT = ops.transpose(dy, R=N, C=Di, batch=B)                                                  # [B,Di,N]
         dgv = torch.empty_like(gv)
-        ops.gemm_nt(RT, dyT, out=dgv, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di)
-        # R = th ph^T / N
-        phT = ops.transpose(ph, R=N, C=Di, batch=B)
-        thT = ops.transpose(th, R=N, C=Di, batch=B)
-        dRT = ops.transpose(dR, R=N, C=N, batch=B)
         dth = torch.empty_like(th)
         dph = torch.empty_like(ph)
-        ops.gemm_nt(dR, phT, out=dth, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
-        ops.gemm_nt(dRT, thT, out=dph, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
+        if ops.SPLIT3_TRANS[0] and ops.f32x3_ok(ad, N, Di):
+            # dgv = R^T dy, dth = dR ph / N, dph = dR^T th / N: the [K, M] / [K, N] operands are read as they are stored (five transposes less)
+            bs = dict(M=N, N=Di, K=N, ldc=Di, batch=B, sc=N * Di)
+            ops.gemm_nt(R, dy, out=dgv, lda=N, ldb=Di, sa=N * N, sb=N * Di, ta=True, tb=True, **bs)
+            ops.gemm_nt(dR, ph, out=dth, lda=N, ldb=Di, sa=N * N, sb=N * Di, tb=True, alpha=1.0 / N, **bs)
+            ops.gemm_nt(dR, th, out=dph, lda=N, ldb=Di, sa=N * N, sb=N * Di, ta=True, tb=True, alpha=1.0 / N, **bs)
+        else:
+            RT = ops.transpose(R, R=N, C=N, batch=B)
+            dyT = ops.transpose(dy, R=N, C=Di, batch=B)                                              # [B,Di,N]
+            ops.gemm_nt(RT, dyT, out=dgv, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di)
+            # R = th ph^T / N
+            phT = ops.transpose(ph, R=N, C=Di, batch=B)
+            thT = ops.transpose(th, R=N, C=Di, batch=B)
+            dRT = ops.transpose(dR, R=N, C=N, batch=B)
+            ops.gemm_nt(dR, phT, out=dth, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
+            ops.gemm_nt(dRT, thT, out=dph, M=N, N=Di, K=N, lda=N, ldb=N, ldc=Di, batch=B, sa=N * N, sb=Di * N, sc=N * Di, alpha=1.0 / N)
         # the transposed input is only an operand of the fp32 (parity-mode) weight-gradient route
         vT = None if (ops.USE_SPLIT3[0] and ops.USE_TN_WGRAD[0] and not ops.FORCE_SIMPLE_GEMM[0]) else ops.transpose(v)
         ops.linear_wgrad(dth, v, mod.theta.weight, mod.theta.bias, xT=vT)

@@ -19,6 +19,8 @@ FORCE_SIMPLE_GEMM = [False]          # tests: route bf16 GEMMs through the VALU 
 ATTN_IMPL = ["auto"]                 # "auto" | "simple"
 USE_SPLIT3 = [False]                 # fp32 GEMMs (the head's fp32 tail) as 3-term bf16 splits on the matrix cores
 SPLIT3_IN_REGISTERS = [os.environ.get("MVULD_SPLIT3_FUSED", "1") != "0"]      # ... split inside the GEMM kernel (0: two split launches + a 3K-deep product)
+SPLIT3_TRANS = [os.environ.get("MVULD_SPLIT3_TRANS", "1") != "0"]             # ... Rs_GCN's R^T dY / dR ph products read their operands as stored (no transposes)
+SPLIT3_WGRAD = [os.environ.get("MVULD_SPLIT3_WGRAD", "1") != "0"]             # ... the head's weight gradients as one such launch (0: two casts + the bf16 kernel)
 USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
 USE_TN_SLABS = [os.environ.get("MVULD_TN_SLABS", "1") != "0"]     # ... whose split contraction (2..8 ways) goes through a slab workspace, not atomics
 
@@ -127,10 +129,17 @@ def grad_of(p: torch.nn.Parameter) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+def f32x3_ok(dtype, M, N):
+    """fp32 products of this size run as in-register bf16 hi / lo splits (mvuld_gemm_nt_f32x3): the only route that takes the ta / tb
+    (transposed-storage operand) arguments of gemm_nt."""
+    return dtype == torch.float32 and USE_SPLIT3[0] and SPLIT3_IN_REGISTERS[0] and not FORCE_SIMPLE_GEMM[0] and M >= 64 and N >= 64
+
+
 def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, out_mode=hip.OUT_STORE, splitk=1,
             out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, batch=1, sa=0, sb=0, sc=0,
-            ldaux=None, saux=0):
-    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias).  2-D contiguous by default; explicit ld/stride for views."""
+            ldaux=None, saux=0, ta=False, tb=False):
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias).  2-D contiguous by default; explicit ld/stride for views.
+    ta / tb (f32x3_ok products only; pass M, N, K and the leading dimensions): that operand is stored [K, M] / [K, N]."""
     M = a.shape[-2] if M is None else M
     K = a.shape[-1] if K is None else K
     N = b.shape[-2] if N is None else N
@@ -149,14 +158,16 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
         raise TypeError("gemm_nt: bias must be fp32")
     if (a.dtype == torch.float32 and b.dtype == torch.float32 and USE_SPLIT3[0] and not FORCE_SIMPLE_GEMM[0] and M >= 64 and N >= 64
             and (aux is None or aux.dtype == out.dtype)):
-        if (SPLIT3_IN_REGISTERS[0] and splitk == 1 and out.dtype == torch.float32
+        if (SPLIT3_IN_REGISTERS[0] and (splitk == 1 or out_mode == hip.OUT_ATOMIC) and out.dtype == torch.float32
                 and (out_mode != hip.OUT_ATOMIC or epi <= hip.EPI_BIAS)):
             # ... split on the way from memory to LDS: one launch, no operand copies (mvuld_gemm_nt_f32x3)
             if hip.TIMING.enabled:
                 hip.TIMING.annotate("gemm_nt_mfma_bf16(split3 fp32)", 6.0 * M * N * K * batch)
             call("gemm_nt_f32x3", ptr(a), lda, sa, ptr(b), ldb, sb, ptr(out), ldc, sc, M, N, K, batch, ptr(bias), epi, ptr(aux), ldaux or 0, saux,
-                 float(alpha), out_mode)
+                 float(alpha), out_mode, 1 if ta else 0, 1 if tb else 0, splitk)
             return out
+        if ta or tb:
+            raise RuntimeError("gemm_nt: transposed-storage operands exist on the in-register split route only (ops.f32x3_ok)")
         # near-fp32 product on the bf16 matrix cores: both operands split into hi/lo bf16 parts concatenated along K
         Kp = (K + 7) // 8 * 8
         ra, rb = M * batch, N * batch
@@ -170,6 +181,8 @@ def gemm_nt(a, b, out=None, bias=None, epi=hip.EPI_NONE, aux=None, alpha=1.0, ou
             call("gemm_nt", ptr(a3), 3 * Kp, M * 3 * Kp, ptr(b3), 3 * Kp, N * 3 * Kp, ptr(out), ldc, sc, M, N, 3 * Kp, batch, ptr(bias), epi,
                  ptr(aux), ldaux or 0, saux, float(alpha), out_mode, splitk, hip.BF16, dt(out), 0)
             return out
+    if ta or tb:
+        raise RuntimeError("gemm_nt: transposed-storage operands exist on the in-register split route only (ops.f32x3_ok)")
     if hip.TIMING.enabled:
         mfma = (a.dtype == torch.bfloat16 and K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and sa % 8 == 0 and sb % 8 == 0
                 and M >= 32 and N >= 32 and not FORCE_SIMPLE_GEMM[0])
@@ -636,6 +649,21 @@ def linear_wgrad(dy, x, w_param, b_param=None, dyT=None, xT=None, bias_out=None)
     bias_out must do so on that stream."""
     M, N = dy.shape
     K = x.shape[1]
+    if (w_param is not None and dy.dtype == torch.float32 and x.dtype == torch.float32 and USE_TN_WGRAD[0] and dyT is None and SPLIT3_WGRAD[0] and f32x3_ok(torch.float32, N, K)
+            and M >= 64 and dy.stride(1) == 1 and x.stride(1) == 1):
+        # fp32 tail of a bf16 model, one launch: dW += dy^T x with both operands read as they are stored ([M, N] = the product's [K, M] operand,
+        # [M, K] = its [K, N] operand), split into bf16 hi / lo parts inside the kernel (near-fp32: better than the bf16-rounded operands of the
+        # route below, which also cost two casts), the token contraction split over workgroups that add into the gradient with atomics
+        if bias_out is not None:
+            colsum_into(dy, bias_out)
+        elif b_param is not None:
+            colsum_into(dy, grad_of(b_param))
+        tiles = math.ceil(N / 64) * math.ceil(K / 64)
+        splitk = max(1, min(math.ceil(M / 256), 512 // max(1, tiles)))
+        hip.TIMING.annotate("gemm_tn_wgrad", 2.0 * M * N * K)
+        gemm_nt(dy, x, out=grad_of(w_param).view(N, K), M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), ldc=K, ta=True, tb=True,
+                out_mode=hip.OUT_ATOMIC, splitk=splitk)
+        return torch.cuda.current_stream(dy.device)
     if (w_param is not None and dy.dtype == torch.float32 and x.dtype == torch.float32 and USE_SPLIT3[0] and USE_TN_WGRAD[0]
             and not FORCE_SIMPLE_GEMM[0] and N % 8 == 0 and K % 8 == 0 and M >= 64 and dy.is_contiguous() and x.is_contiguous()):
         # fp32 tail of a bf16 model: its weight gradients are formed like every other weight gradient of the model, from

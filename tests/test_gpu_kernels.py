@@ -81,6 +81,7 @@ def test_gemm_nt_fp32_split_in_registers(gpu, M, N, K, batch):
     try:
         assert ops.SPLIT3_IN_REGISTERS[0]
         out = ops.gemm_nt(A, B_, out=torch.empty(batch, M, N, device=gpu), **kw)
+        out0 = out
         assert rel(out, ref.float()) < 3e-5, rel(out, ref.float())
         ops.SPLIT3_IN_REGISTERS[0] = False
         try:
@@ -97,6 +98,17 @@ def test_gemm_nt_fp32_split_in_registers(gpu, M, N, K, batch):
         acc = AX.clone()
         ops.gemm_nt(A, B_, out=acc, out_mode=hip.OUT_ACCUM, alpha=0.5, **kw)
         assert rel(acc, (0.5 * ref + auxv.double()).float()) < 3e-5
+        # operands stored transposed ([K, M] / [K, N]): the same product without a transpose pass, in all four combinations
+        AT, BT = A.transpose(1, 2).contiguous(), B_.transpose(1, 2).contiguous()
+        for ta, tb in ((True, False), (False, True), (True, True)):
+            kt = dict(kw, lda=M if ta else K, ldb=N if tb else K, sa=M * K, sb=N * K)
+            o2 = ops.gemm_nt(AT if ta else A, BT if tb else B_, out=torch.empty(batch, M, N, device=gpu), ta=ta, tb=tb, **kt)
+            assert rel(o2, out0) < 2e-6, (ta, tb, rel(o2, out0))
+        # contraction splits adding into C with atomics (the weight-gradient form dW += dY^T X: both operands stored [K, .])
+        if batch == 1:
+            accw = AX[0].clone()
+            ops.gemm_nt(AT[0], BT[0], out=accw, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, ta=True, tb=True, out_mode=hip.OUT_ATOMIC, splitk=3)
+            assert rel(accw, (ref[0] + auxv[0].double()).float()) < 3e-5
     finally:
         ops.USE_SPLIT3[0] = False
 
