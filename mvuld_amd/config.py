@@ -165,6 +165,7 @@ _DEFAULTS = {
         "DATA_ROOT": "",           # a corpus directory in the reference's file formats (data/bigvul_dataset.py: BigVulFiles) instead
         "SYNTH_TRAIN": 256, "SYNTH_VAL": 64, "SYNTH_TEST": 64,
         "SEQ_LEN": 512, "NODES_LO": 150, "NODES_HI": 250,
+        "LINE_LEN": 64,            # BigVulFiles: per-line token ids of every function are padded (pad id 1) / truncated to this width
         # HIDDEN_DROPOUT / ATTN_DROPOUT: HF RobertaConfig defaults (unixcoder.py:107-110 builds the model from that config); active
         # whenever the text encoder is in train() mode, as it is in the fused step
         "TEXT": {"VOCAB": 51416, "HIDDEN": 768, "LAYERS": 12, "HEADS": 12, "INTERMEDIATE": 3072, "MAX_POS": 1026,

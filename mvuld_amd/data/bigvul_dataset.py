@@ -64,6 +64,10 @@ class BigVulFiles(Dataset):
         import os
         self.root, self.fused, self.graph_type = str(root), fused, graph_type
         self.seq_len = config.FUSED.SEQ_LEN
+        # width every graph's per-line ids are padded (pad id 1) or truncated to, so that functions whose npz files hold different Lk
+        # batch together (graph.batch concatenates ndata along dim 0)
+        self.line_len = int(config.FUSED.LINE_LEN)
+        self._node_source = None          # "line_token_ids" | "node_emb": one node-feature source per corpus (graph.batch keys by the first graph)
         self.items = []
         with open(os.path.join(self.root, f"{split}.txt")) as f:
             for line in f:
@@ -94,16 +98,26 @@ class BigVulFiles(Dataset):
         g, code = build_function_graph(nodes_json, edges_json, pos, self.graph_type)
         lineno = g.ndata["_lineno"].to(torch.int64).tolist()
         lt, ne = self._path("line_token_ids", f"{_id}.npz"), self._path("node_emb", f"{_id}.npz")
-        if os.path.exists(lt):
+        source = "line_token_ids" if os.path.exists(lt) else ("node_emb" if os.path.exists(ne) else None)
+        if source is not None and self._node_source not in (None, source):
+            raise ValueError(f"{_id}: node features come from {source}/ but earlier functions of this corpus used {self._node_source}/ -- "
+                             f"a corpus must use ONE node-feature source (graphs of a batch share their ndata keys)")
+        if source is not None:
+            self._node_source = source
+        if source == "line_token_ids":
             z = np.load(lt)
             row = {int(l): k for k, l in enumerate(z["lineno"].tolist())}
-            ids = torch.ones((len(lineno), z["ids"].shape[1]), dtype=torch.int64)              # pad id 1; a line without ids = one <s>
+            L = self.line_len
+            ids = torch.ones((len(lineno), L), dtype=torch.int64)                               # pad id 1; a line without ids = one <s>
             ids[:, 0] = 0
+            zi = z["ids"].astype(np.int64)
+            w = min(L, zi.shape[1])                                                             # pad (id 1) or truncate to FUSED.LINE_LEN
             for k, l in enumerate(lineno):
                 if l in row:
-                    ids[k] = torch.from_numpy(z["ids"][row[l]].astype(np.int64))
+                    ids[k, :w] = torch.from_numpy(zi[row[l], :w])
+                    ids[k, w:] = 1
             g.ndata["_token_ids"] = ids
-        elif os.path.exists(ne):
+        elif source == "node_emb":
             z = np.load(ne)
             row = {int(l): k for k, l in enumerate(z["lineno"].tolist())}
             emb = torch.zeros((len(lineno), z["emb"].shape[1]), dtype=torch.float32)

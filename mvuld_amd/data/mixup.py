@@ -7,6 +7,10 @@ the host from numpy's global generator with the SAME calls in the SAME order as 
 ``rand_bbox`` (so a run seeded like the reference's, main.py: ``np.random.seed(seed)``, draws the same sequence), and the mixing itself on
 the device (``mvuld_mixup_batch``: images and label-smoothed soft targets).  Parity with timm itself is unpinned (library absent); the
 arithmetic is checked against a torch restatement of the same formulas in the tests.
+
+Attribution: ``rand_bbox``, ``rand_bbox_minmax``, ``cutmix_bbox_and_lam`` and the per-batch parameter draw follow timm 0.4.12
+``timm/data/mixup.py`` (Copyright 2020 Ross Wightman, Apache License 2.0, https://github.com/rwightman/pytorch-image-models) closely on
+purpose -- the numpy draws have to come in timm's order for a seeded run to reproduce the reference's batches.
 """
 import numpy as np
 import torch

@@ -370,10 +370,19 @@ class PatchMerging(nn.Module):
 
 
 class BasicLayer(nn.Module):
+    _warned_checkpoint = False
+
     def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=True, drop=0., attn_drop=0.,
                  drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False, pretrained_window_size=0):
         super().__init__()
         self.dim, self.input_resolution, self.depth, self.use_checkpoint = dim, input_resolution, depth, use_checkpoint
+        if use_checkpoint and not BasicLayer._warned_checkpoint:
+            # reference: swin_transformer_v2.py:428-431 wraps every block in torch.utils.checkpoint (flag: main_bigvul.py:97).  Results are
+            # identical without it; this build keeps every block's saved tensors (12.8 GB at batch 32 of the 288 GB) and never recomputes.
+            import warnings
+            warnings.warn("--use-checkpoint / TRAIN.USE_CHECKPOINT is accepted for CLI compatibility and IGNORED: activation checkpointing is "
+                          "not implemented (saved activations fit HBM: ~22 GB peak at batch 32); outputs and gradients are unaffected")
+            BasicLayer._warned_checkpoint = True
         self.blocks = nn.ModuleList([
             SwinTransformerBlock(dim=dim, input_resolution=input_resolution, num_heads=num_heads, window_size=window_size,
                                  shift_size=0 if (i % 2 == 0) else window_size // 2, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,

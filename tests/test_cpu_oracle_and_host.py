@@ -584,7 +584,9 @@ def test_bigvul_files_dataset_reads_the_reference_file_formats(tmp_path):
         assert np.array_equal(g.ndata["pos_emb"][k].numpy(), want)
     z = np.load(os.path.join(root, "line_token_ids", "12.npz"))
     row = {int(l): k for k, l in enumerate(z["lineno"].tolist())}
-    assert g.ndata["_token_ids"].shape == (len(ln), 16) and all(np.array_equal(g.ndata["_token_ids"][k].numpy(), z["ids"][row[l]]) for k, l in enumerate(ln))
+    tk = g.ndata["_token_ids"]                                  # [nodes, FUSED.LINE_LEN]: the file's 16 ids per line, then the pad id
+    assert tk.shape == (len(ln), config.FUSED.LINE_LEN) and bool((tk[:, 16:] == 1).all())
+    assert all(np.array_equal(tk[k, :16].numpy(), z["ids"][row[l]]) for k, l in enumerate(ln))
     assert img.dtype == torch.uint8 and np.array_equal(img.numpy(), np.asarray(Image.open(os.path.join(root, "images", "12.png")).convert("RGB")))
     raw = np.load(os.path.join(root, "token_ids", "12.npy"))
     assert ids.shape == (48,) and np.array_equal(ids[:40].numpy(), raw) and bool((ids[40:] == 1).all())      # padded to SEQ_LEN with the pad id
@@ -592,6 +594,20 @@ def test_bigvul_files_dataset_reads_the_reference_file_formats(tmp_path):
     gb, imgs, idb, y = collate([ds[0], ds[1]])
     assert isinstance(imgs, list) and [int(v) for v in gb.batch_num_nodes()] == [int(ds[0][0].batch_num_nodes()[0]), int(g.batch_num_nodes()[0])]
     assert idb.shape == (2, 48)
+    # functions whose per-line id files have DIFFERENT widths batch together: a wider file is truncated, a narrower one padded
+    z13 = np.load(os.path.join(root, "line_token_ids", "13.npz"))
+    wide = np.concatenate([z13["ids"], np.full((z13["ids"].shape[0], 80), 7, dtype=z13["ids"].dtype)], 1)      # 96 ids per line > LINE_LEN
+    np.savez(os.path.join(root, "line_token_ids", "13.npz"), lineno=z13["lineno"], ids=wide)
+    g13 = ds[2][0]
+    assert g13.ndata["_token_ids"].shape[1] == config.FUSED.LINE_LEN and bool((g13.ndata["_token_ids"][:, 16:] == 7).any())
+    gb2 = collate([ds[1], ds[2]])[0]
+    assert gb2.ndata["_token_ids"].shape == (g.number_of_nodes() + g13.number_of_nodes(), config.FUSED.LINE_LEN)
+    # ... and a corpus that mixes the two node-feature sources is refused with a clear error, not a KeyError inside collate
+    os.remove(os.path.join(root, "line_token_ids", "14.npz"))
+    np.savez(os.path.join(root, "node_emb", "14.npz") if os.path.isdir(os.path.join(root, "node_emb")) or not os.makedirs(os.path.join(root, "node_emb"))
+             else None, lineno=z13["lineno"], emb=np.zeros((len(z13["lineno"]), 768), dtype=np.float32))
+    with pytest.raises(ValueError, match="ONE node-feature source"):
+        ds[3]
     # head-only mode: the tuple ImageList.__getitem__ returns (data_list.py:141)
     dh = BigVulFiles(root, "val", config, fused=False)
     gh, ie, te, lh = dh[0]
