@@ -269,6 +269,14 @@ int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW, int res, 
                         const float* sample_scale, int dtype, mvuld_stream_t stream);
 /* passes: 1 = delta + dQ + dK/dV, 2 = bias-table gradient (mode 0; reads ws_delta / ws_qt written by pass 1), 3 = both.
  * The bias-table gradient feeds nothing else in backward, so a caller may issue pass 2 later, on another stream. */
+/* Round 4: the FUSED window backward.  For mode 0, head_dim 32, ws % 4 == 0 and ws <= 28 (SwinV2-base stages 0-2) one kernel forms dQ, dK, dV
+ * and the bias-table gradient from a single recomputation of the scores (swin_transformer_v2.py:140-179 backward; the three passes above
+ * recompute S, exp and dP once each).  mvuld_attn_bwd_fused_active(mode, hd, ws) = 1 says that mvuld_attn_bwd_mfma will take the geometry that
+ * way: the caller then issues ONE call with passes = 3 and a ws_part of mvuld_attn_bwd_mfma_workspace_bytes (required, not optional);
+ * a call with passes = 2 alone returns without work.  mvuld_set_attn_bwd_fused(0) / MVULD_ATTN_BWD_FUSED=0 keep the three passes
+ * (results agree to the rounding of the bf16 operands and of the order of fp32 sums; tests compare both with the fp32 restatement). */
+int mvuld_attn_bwd_fused_active(int mode, int hd, int ws);
+int mvuld_set_attn_bwd_fused(int on);
 
 /* Continuous position bias table and its backward: swin_transformer_v2.py:159-163 (cpb_mlp over relative_coords_table) */
 int mvuld_cpb_table_fwd(const float* coords, const float* W1, const float* b1, const float* W2, float* hidden,

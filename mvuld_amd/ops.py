@@ -964,7 +964,9 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
         args = (*g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
                 ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt))
         wg = wgrad_stream_for_current() if g.mode == 0 else None
-        if g.mode != 0 or wg is None:
+        # round 4: the fused window backward forms the table gradient in the same pass as dQ / dK / dV -- one call, this stream
+        fused = g.mode == 0 and hip.LIB.fn("mvuld_attn_bwd_fused_active")(0, g.hd, g.ws) == 1
+        if g.mode != 0 or wg is None or fused:
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
             call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed,
                  rng_offset_ptr(), ss, dt(qkv))

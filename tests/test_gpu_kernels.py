@@ -731,6 +731,50 @@ def test_window_attention_skips_droppath_dropped_samples(gpu, res, ws, shift, H)
     assert rel(skip[3], full[3]) < 1e-5 and rel(skip[4], full[4]) < 1e-5          # sums of float atomics: order not fixed
 
 
+@pytest.mark.parametrize("res,ws,shift,H,ls_lo,ls_hi", [(56, 28, 14, 2, 1.5, 3.0), (28, 28, 0, 3, 1.5, 5.0), (112, 28, 14, 1, 1.5, 3.0), (16, 8, 4, 2, 1.5, 3.0),
+                                                        (24, 12, 6, 1, 1.5, 3.0), (8, 4, 0, 2, 1.5, 3.0), (40, 20, 10, 1, 1.5, 5.0), (48, 24, 12, 2, 2.0, 2.5)])
+def test_fused_window_backward(gpu, res, ws, shift, H, ls_lo, ls_hi):
+    """Round 4: attn_bwd_fused_win_k -- dQ, dK, dV, d(bias table) and d(logit_scale) from ONE recomputation of the scores per (query, key)
+    pair (row-aligned 32 x 32 blocks, key rows resident per wave, dS through LDS once for dQ, the table gradient folded with whole-wave DPP
+    shifts) -- against (a) the fp32 restatement of swin_transformer_v2.py:140-179,245-268 at the bounds of test_swin_window_attention and
+    (b) the three-pass matrix-core backward (mvuld_set_attn_bwd_fused(0)), which rounds the same operands to bf16: the two agree to the
+    rounding of bf16 P / dS and of the order of the fp32 sums.  Geometries: the three SwinV2-base window stages' shapes (one window, 4 and 16
+    windows, shifted and not), windows with fewer rows than the waves own (4, 8, 12, 20, 24: waves with 0-6 key rows), heads past the
+    ln(100) clamp (no d(logit_scale) there) and past the tau bound of the vertical-split skip."""
+    from mvuld_amd import ops, hip
+    B, hd = 2, 32
+    C = H * hd
+    T2 = (2 * ws - 1) ** 2
+    qkv = rt(T("fq", (B * res * res, 3 * C), -2, 2), torch.bfloat16)
+    table, ls = T("ft", (T2, H), 0.0, 16.0), T("fls", (H,), ls_lo, ls_hi)
+    dout = rt(T("fdo", (B * res * res, C)), torch.bfloat16)
+    q_, t_, l_ = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+    ref = _swin_attn_ref(q_, t_, l_, B, H, hd, res, ws, shift)
+    ref.backward(dout)
+    g = ops.AttnGeom(0, B, H, hd, ws * ws, (res // ws) ** 2, res, ws, shift)
+    gq, gt, gl, gdo = dev(qkv, torch.bfloat16), dev(table), dev(ls), dev(dout, torch.bfloat16)
+    out, lse = ops.attn_fwd(g, gq, gt, gl)
+    assert hip.LIB.fn("mvuld_attn_bwd_fused_active")(0, hd, ws) == 1
+    got = {}
+    try:
+        for fused in (1, 0):
+            hip.LIB.fn("mvuld_set_attn_bwd_fused")(fused)
+            dtab, dls = torch.zeros((T2, H), device=gpu), torch.zeros(H, device=gpu)
+            dqkv = ops.attn_bwd(g, gq, out, gdo, lse, gt, gl, None, dtab, dls)
+            torch.cuda.synchronize()
+            got[fused] = (dqkv, dtab, dls)
+    finally:
+        hip.LIB.fn("mvuld_set_attn_bwd_fused")(1)
+    k = 4
+    for part, (lo, hi) in {"dq": (0, C), "dk": (C, 2 * C), "dv": (2 * C, 3 * C)}.items():
+        assert bool(torch.isfinite(got[1][0].float()).all())
+        assert rel(got[1][0][:, lo:hi], q_.grad[:, lo:hi]) < tol(torch.bfloat16) * k, (part, rel(got[1][0][:, lo:hi], q_.grad[:, lo:hi]))
+        assert rel(got[1][0][:, lo:hi], got[0][0][:, lo:hi]) < 2e-2, (part, rel(got[1][0][:, lo:hi], got[0][0][:, lo:hi]))
+    assert rel(got[1][1], t_.grad) < tol(torch.bfloat16) * k, rel(got[1][1], t_.grad)
+    assert rel(got[1][1], got[0][1]) < 1e-2, rel(got[1][1], got[0][1])
+    assert rel(got[1][2], l_.grad) < 0.3 and rel(got[1][2], got[0][2]) < 5e-2, (rel(got[1][2], l_.grad), rel(got[1][2], got[0][2]))
+
+
 @pytest.mark.parametrize("dtype,impl", [(torch.float32, "simple"), (torch.bfloat16, "simple"), (torch.bfloat16, "auto")])
 @pytest.mark.parametrize("hd,L", [(32, 100), (64, 100), (64, 512)])
 def test_padmask_attention(gpu, dtype, impl, hd, L):
