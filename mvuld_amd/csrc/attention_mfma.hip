@@ -16,173 +16,7 @@
 // up to ~155 KB of the 160 KB.  The shift mask comes from 3x3 region ids: no [N,N] tensor ever exists.  P is recomputed
 // in backward from the saved log-sum-exp; delta = rowsum(dO * O) comes from a small pre-kernel.  d(bias table) is
 // accumulated with LDS float atomics per workgroup and flushed with one global atomic per touched entry.
-#include "common.h"
-#include <stdlib.h>
-#include <atomic>
-
-struct AttnGeom {
-    int mode, B, H, N, nW, res, ws, shift;
-    float scale;
-    const int* cu;          // MODE 1, packed (varlen) sequences: cu[b] .. cu[b+1] are the token rows of sequence b; null = dense [B, N]
-    int64_t tok0;           // MODE 1: first token row of the workgroup's sequence (set inside the kernels)
-    // MODE 1, attention-probability dropout (HF attention_probs_dropout_prob): keep(b,h,q,k) = hash(seed, element) >= thr, kept
-    // probabilities scaled by inv = 1/(1-p); thr = 0 switches it off.  Counter-based: the backward passes regenerate the mask.
-    unsigned drop_thr, drop_seed;
-    float drop_inv;
-    const uint64_t* drop_off;   // optional device-resident step counter mixed into the seed (hipGraph replays draw fresh masks)
-    // Tail balancing (am_plan): the first `whole` workgroups (in launch order) take one (window, head) each, the workgroups behind them
-    // split the remaining ones `split` ways; whole = 0: every (window, head) is split `split` ways.
-    int whole = 0;
-    // MODE 0, shifted windows: skip the key blocks (query blocks) that lie wholly across a window's vertical mask split from the wave's
-    // queries (keys) -- every pair in them carries the -100 of swin_transformer_v2.py:245-268 (am_ysplit); 0 = compute them as every other pair
-    int yskip = 0;
-    // MODE 0, optional [B] per-sample scale of the residual branch this attention belongs to (DropPath, swin_transformer_v2.py:301): a sample
-    // whose scale is exactly 0 contributes nothing downstream (forward: its output is multiplied by 0; backward: its d(out) IS 0), so its
-    // workgroups write zeros and return instead of computing them
-    const float* sscale = nullptr;
-};
-__device__ __forceinline__ bool am_dropped(const AttnGeom& g, int b) { return g.mode == 0 && g.sscale != nullptr && g.sscale[b] == 0.f; }
-__device__ __forceinline__ unsigned am_seed(const AttnGeom& g) {
-    return g.drop_off ? g.drop_seed ^ (unsigned)(g.drop_off[0] * 0x9E3779B97F4A7C15ULL >> 32) : g.drop_seed;
-}
-// Round 3: ONE 32-bit hash serves the two keys of an aligned pair (2j, 2j+1) of a query row -- the counter is row * ceil(N/2) + j, the
-// even key takes bits 0..14, the odd key bits 16..30, and a key is kept when its 15-bit field >= thr15 = round(p * 2^15) (keep
-// probability exactly 1 - thr15 / 2^15, the scale is its reciprocal).  The two 32-bit multiplies of the hash were most of the text
-// encoder's attention VALU work (301 vs 108 vector instructions per 64-key forward block with / without dropout).  drop_thr carries
-// (thr15 - 1) in both halves: the packed 16-bit subtraction (thr15 - 1) - field is negative exactly where the key is kept, and its
-// sign, smeared over the half by a packed arithmetic shift, is the keep mask of the packed bf16 probability pair.
-__device__ __forceinline__ unsigned am_hash(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-typedef short __attribute__((ext_vector_type(2))) s16x2_t;
-__device__ __forceinline__ unsigned am_keep2(unsigned pairctr, unsigned seed, unsigned thr2m1) {          // 0xFFFF in the halves that are kept
-    const unsigned f = am_hash(pairctr ^ seed) & 0x7FFF7FFFu;
-    const s16x2_t d = __builtin_bit_cast(s16x2_t, thr2m1) - __builtin_bit_cast(s16x2_t, f);
-    return __builtin_bit_cast(unsigned, d >> (s16x2_t){15, 15});
-}
-// quad_perm [1, 0, 3, 2]: the value of the lane's neighbour (lane ^ 1)
-__device__ __forceinline__ unsigned am_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
-
-typedef bf16 __attribute__((ext_vector_type(8))) bf16x8_t;
-typedef bf16 __attribute__((ext_vector_type(4))) bf16x4_t;
-typedef float __attribute__((ext_vector_type(4))) f32x4_t;
-// Explicit two-wide fp32 math for the softmax fix-ups: left to itself the SLP vectoriser pairs elements (1,2),(3,4).. of an
-// accumulator quad, and every v_pk_mul_f32 then costs two v_mov to build its operand pair plus v_alignbit / v_perm to re-pack the
-// bf16 fragment (28 of the 98 VALU instructions of a 64-key dQ block).  Register pairs (0,1),(2,3) of an MFMA result are aligned.
-typedef float __attribute__((ext_vector_type(2))) f32x2_t;
-typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
-typedef bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
-__device__ __forceinline__ unsigned am_pk(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
-#ifndef AM_X
-#define AM_X 0      // timing experiments (tools/attn_variants.sh): 1 = no exp, 2 = no bias reads, 3 = no transposed reads; bias-table pass: 4 = K/V fragments read once per item, 5 = q-side rows fetched once per item
-#endif
-__device__ __forceinline__ f32x2_t am_exp2(f32x2_t v) {
-#if AM_X == 1
-    return v * 0.001f;
-#else
-    return (f32x2_t){__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
-#endif
-}
-
-#define LN100 4.605170185988092f
-#define NEG_BIG -1.0e30f
-
-__device__ __forceinline__ int64_t am_token(const AttnGeom& g, int b, int w, int n) {
-    if (g.mode == 1) return g.tok0 + n;
-    const int nwx = g.res / g.ws;
-    const int sy = (w / nwx) * g.ws + n / g.ws, sx = (w % nwx) * g.ws + n % g.ws;
-    int oy = sy + g.shift, ox = sx + g.shift;
-    if (oy >= g.res) oy -= g.res;
-    if (ox >= g.res) ox -= g.res;
-    return ((int64_t)b * g.res + oy) * g.res + ox;
-}
-__device__ __forceinline__ int am_rid(const AttnGeom& g, int s) { return s < g.res - g.ws ? 0 : (s < g.res - g.shift ? 1 : 2); }
-// A shifted window mixes mask regions only in the last row / column of windows (where the rolled image wraps); every other window
-// is one region (id 0) and takes the unmasked loops: 9 of the 16 windows of stage 0, 1 of the 4 of stage 1.
-__device__ __forceinline__ bool am_window_masked(const AttnGeom& g, int w) {
-    const int nwx = g.res / g.ws;
-    return g.shift > 0 && ((w / nwx) == nwx - 1 || (w % nwx) == nwx - 1);
-}
-// The last ROW of windows of a shifted block holds two vertical mask regions: window rows below ws - shift come from the bottom of the
-// image, the rest from its (rolled-in) top, and the -100 on every pair across the split leaves them exp2(-144 + (s - m)) of the row's
-// largest probability.  With cosine logits |q.k| <= tau and a bias in (0, 16) that is below 2^-57 for tau <= 22: under the fp32
-// resolution of every accumulator it would be added to, so whole tiles of such pairs are skipped -- same bits out -- while a head whose tau
-// has grown past the bound keeps computing them (as the reference's finite -100 demands).  Returns the split as a token index of the
-// window's row-major order, or INT_MAX (no split in this window / tau too large / switched off).  The horizontal split of the last
-// COLUMN of windows cannot be skipped tile-wise: every 16-token tile of a row-major window holds tokens of both of its sides.
-#define AM_YSKIP_TAU 22.0f
-__device__ __forceinline__ int am_ysplit(const AttnGeom& g, int w, float tau) {
-    const int nwx = g.res / g.ws;
-    if (g.mode != 0 || g.shift <= 0 || !g.yskip || !(tau <= AM_YSKIP_TAU) || (w / nwx) != nwx - 1) return 0x7fffffff;
-    return (g.ws - g.shift) * g.ws;
-}
-// query tokens [q0, q1) and key tokens [k0, k1) on opposite sides of the split
-__device__ __forceinline__ bool am_yskip(int ys, int q0, int q1, int k0, int k1) { return (q1 <= ys && k0 >= ys) || (q0 >= ys && k1 <= ys); }
-// per-token info word.  MODE 0: (iy*(2ws-1)+ix) | region << 16 ; MODE 1: validity in bit 0.  Bit 30 marks a padding row
-// (all other fields then hold safe in-range values, so the hot loops stay branch-free).
-#define AM_PAD (1 << 30)
-__device__ __forceinline__ int am_info(const AttnGeom& g, const int* __restrict__ valid, int b, int w, int n) {
-    if (n >= g.N) return AM_PAD;
-    if (g.mode == 1) return (valid == nullptr || valid[g.tok0 + n]) ? 1 : 0;
-    const int nwx = g.res / g.ws;
-    const int iy = n / g.ws, ix = n % g.ws;
-    int reg = 0;
-    if (g.shift > 0) reg = am_rid(g, (w / nwx) * g.ws + iy) * 3 + am_rid(g, (w % nwx) * g.ws + ix);
-    return (iy * (2 * g.ws - 1) + ix) | (reg << 16);
-}
-
-// MODE 1: point the geometry at the workgroup's sequence.  Dense: rows b*N .. b*N+N-1.  Packed: rows cu[b] .. cu[b+1]-1, g.N becomes
-// the sequence's own length (<= the launch's N, which sizes LDS and the lse rows).  Returns the extent (multiple of 32) the
-// staging and key / query loops run over; 0 = empty sequence.
-__device__ __forceinline__ int am_localize(AttnGeom& g, int b, int Npad) {
-    if (g.mode != 1) return Npad;
-    if (g.cu == nullptr) { g.tok0 = (int64_t)b * g.N; return Npad; }
-    g.tok0 = g.cu[b];
-    g.N = g.cu[b + 1] - g.cu[b];
-    return min(Npad, (g.N + 31) / 32 * 32);
-}
-
-// reductions over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48 -- VALU only (v_permlane16/32_swap)
-__device__ __forceinline__ float sum4g(float v) {
-    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-__device__ __forceinline__ float max4g(float v) {
-    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-
-union U8 { uint4 u; bf16x8_t v; bf16 e[8]; };
-union U4 { uint2 u; bf16x4_t v; bf16 e[4]; };
-
-// Stage `rows` token rows (HD wide, from column `coloff` of a [tokens, rowstride] matrix) starting at n0 into the
-// row-major LDS image rm[rows][HD+8], with optional L2 normalisation and scale.  Rows >= N are zero.  Four 16-byte loads
-// are kept in flight per thread.
-// XCD-aware order: workgroups b, b+8, ... share an XCD and its L2.  Giving each XCD a contiguous run of (window, head, part)
-// items keeps the heads of one window -- which read interleaved 64/128-byte column slices of the same qkv rows -- on one L2.
-__device__ __forceinline__ int am_xcd_order(int bid, int total) {
-    const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
-// (launch-order block index) -> (window x head index, part, parts): XCD-contiguous order inside the unsplit and inside the split range
-__device__ __forceinline__ void am_part(const AttnGeom& g, int split, int& bwh, int& part, int& parts) {
-    const int bx = blockIdx.x, total = gridDim.x;
-    if (g.whole > 0) {
-        if (bx < g.whole) { bwh = am_xcd_order(bx, g.whole); part = 0; parts = 1; return; }
-        const int r = am_xcd_order(bx - g.whole, total - g.whole);
-        bwh = g.whole + r / split; part = r % split; parts = split;
-        return;
-    }
-    const int bid = am_xcd_order(bx, total);
-    part = bid % split; bwh = bid / split; parts = split;
-}
-
+#include "attention_common.h"
 // LDS image of a [rows][HD] bf16 operand tile, read two ways: 16-byte fragments of 16 consecutive rows (ds_read_b128) and transposed
 // 8-byte pieces of 4 x 4 consecutive rows (ds_read_b64_tr_b16: 16 lanes = 4 rows x 32 bytes).
 //   PAD (HD = 64, and the bias-gradient pass): rows padded to HD + 8 elements.  At HD = 64 (144 B = 36 banks) both patterns are
@@ -252,8 +86,6 @@ __device__ __forceinline__ bf16x8_t read_tr(const bf16* rm, int d0, int r0, int 
 // ------------------------------------------------------------------------------------------------ forward
 // Scores live in log2 units (log2(e) is folded into q~, the bias table and the mask constants) so the softmax uses bare
 // v_exp_f32.  Per-key info word (Kinfo): MODE 0: 4*(iy*(2w-1)+ix) | region << 16 (| AM_PAD), MODE 1: valid (| AM_PAD).
-#define LOG2E 1.4426950408889634f
-#define LN2 0.6931471805599453f
 
 // Score fix-ups.  The continuous position bias does not cost a VALU add per score: it is the INITIAL ACCUMULATOR of the S = K.Q^T
 // MFMA (am_bias4).  A lane's four accumulator rows are four consecutive window positions n0 .. n0+3 with n0 % 4 == 0; when the
@@ -1518,415 +1350,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_win_k(AttnGeom g, const bf16* _
     }
 }
 
-// ================================================================================================ fused window backward (round 4)
-// MODE 0, head_dim 32, window side ws <= 28 with ws % 4 == 0 (SwinV2-base stages 0-2: 28 x 28 windows): dQ, dK, dV AND the bias-table
-// gradient from ONE recomputation of S and dP per (query, key) pair -- the three-pass backward above recomputes the scores, the
-// exponentials and dP once per pass (dQ 4.2 + dK/dV 5.3 + bias table 5.5 ms of the round-3 step).  Structure (cdna_hip_programming.md,
-// "Attention backward" and "An accumulator tile as the next MFMA's operand"):
-//   * tiles are aligned to IMAGE ROWS of the window: a block = one query row x one key row, 32 x 32 slots of which ws x ws are real
-//     (v_mfma_f32_32x32x16_bf16).  That costs (32 / 28)^2 of padded scores and buys: the relative-position offset of a block is ONE dy,
-//     so a lane's bias words are consecutive table words of one table row, the vertical mask region is block-uniform, and the
-//     bias-table gradient of a block is a diagonal fold of the dS tile into ONE table row.
-//   * one workgroup of 4 waves (one per SIMD, up to 512 registers each) per (window, head).  Wave w OWNS key rows 7w .. 7w+6: their
-//     dK^T and dV^T tiles stay in 224 accumulator registers for the whole sweep, so dK / dV need no sum across waves.  All waves sweep
-//     the query rows together; the q-side tile of a row (q~, dO, -lse, -delta; delta = rowsum(dO o O) is formed here) is fetched one
-//     row ahead and shared through a double-buffered 4.25 KB LDS tile.
-//   * the key is on the LANE in S = Q~.K^T and dP = dO.V^T (rows = queries in the registers), so P and dS are, converted to bf16 pairs,
-//     directly the B operands of dV^T += dO^T.P and dK^T += Q~^T.dS; only dS crosses LDS, once, wave-privately (8-byte stores of
-//     register quads into a [key][query] image, ds_read_b64_tr_b16 back), for dQ^T += K^T.dS^T.  -lse and the bias are the initial
-//     accumulator of S, -delta that of dP.
-//   * dQ of a query row is the sum of the four waves' partial tiles: 4.5 KB per wave through LDS, summed by slices (8 queries per wave),
-//     which also carry the cosine-normalisation backward and d(logit_scale).
-//   * d(bias table): dB[dy][dx] = sum of dS over pairs with that offset.  Within a block dx = qx - kx: the four queries of a register
-//     quad are folded along the diagonal with whole-wave DPP shifts (wave_shr:1, tools/microbench/dpp_wave_shift.hip: gfx950 executes
-//     the GFX9 whole-wave shifts) -- 3 shifted adds per quad, no LDS -- and because a wave's key rows are consecutive, block (qy, ky)
-//     and block (qy + 1, ky + 1) share dy: the folded quads ride a 7-block diagonal chain in registers and touch the LDS table once
-//     per step instead of once per block.
-typedef float __attribute__((ext_vector_type(16))) f32x16_t;
-#define AF_RPW 7            // key rows per wave
-#define AF_WAVES 4
-#define AF_DS 60            // row stride (words) of the LDS table gradient: indices 8g + 4h - kx + ws - 1 <= 58
-#define AF_PQ 36            // row stride (words) of a dQ partial tile: 8 consecutive rows of a 16-byte store hit 32 different banks
-// [rows][32] bf16 image with 64-byte rows; the 16-byte chunk c of a row whose position inside its window row (or tile) is x sits at
-// chunk c ^ ((x >> 2) & 3): 32 consecutive rows of a 16-byte fragment read, and the 4-row blocks of a transposed read, are conflict free
-__device__ __forceinline__ int af_off(int row, int x, int chunk) { return row * 32 + ((chunk ^ ((x >> 2) & 3)) << 3); }
-__device__ __forceinline__ bf16x8_t af_tr(const bf16* img, int offA, int offB) {
-    typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(img + offA));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(img + offB));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-// whole-wave shift by one lane away from lane 0 (wave_shr:1): lane l receives lane l - 1, lane 0 receives 0
-__device__ __forceinline__ float af_shr1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-__host__ __device__ inline size_t af_lds_bytes(int ws) {
-    const int N = ws * ws, W2 = 2 * ws - 1;
-    return (size_t)2 * (N - ws + 32) * 64                    // K^, V images
-         + (size_t)(((W2 * W2 + 64 + 3) & ~3) + 64) * 4      // bias table (log2 units) + slack behind the last row (16-byte multiple) + the -inf row of padding keys
-         + (size_t)W2 * AF_DS * 4                            // table gradient
-         + (size_t)2 * (2 * 32 * 32 * 2 + 2 * 32 * 4)        // q-side tiles of two query rows: q~, dO, -lse, -delta
-         + (size_t)AF_WAVES * 32 * 32 * 2                    // dS transposition images
-         + (size_t)AF_WAVES * 32 * AF_PQ * 4                 // dQ partial tiles
-         + 64;
-}
-
-template <bool MASK>
-__global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
-                                                                     const float* __restrict__ logit_scale, const bf16* __restrict__ outp,
-                                                                     const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                                     bf16* __restrict__ dqkv, float* __restrict__ part_out,
-                                                                     float* __restrict__ dlogit_scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HD = 32;
-    const int ws = g.ws, N = g.N, W2 = 2 * ws - 1, T2 = W2 * W2;
-    const int KR = N - ws + 32;                                   // image rows: the last key row is read 32 slots wide
-    bf16* Ki = (bf16*)smem;
-    bf16* Vi = Ki + (size_t)KR * 32;
-    float* tab = (float*)(Vi + (size_t)KR * 32);                  // [T2 + 64 (+ pad)] then negrow[64]
-    float* negrow = tab + ((T2 + 64 + 3) & ~3);
-    float* dtab = negrow + 64;                                    // [W2][AF_DS]
-    bf16* Qs = (bf16*)(dtab + W2 * AF_DS);                        // [2][32][32]
-    bf16* Ds = Qs + 2 * 1024;                                     // [2][32][32]
-    float* Nl = (float*)(Ds + 2 * 1024);                          // [2][32]  -lse * log2(e)   (padding queries: -inf)
-    float* Nd = Nl + 64;                                          // [2][32]  -delta
-    bf16* Tb = (bf16*)(Nd + 64);                                  // [waves][32 keys][32 queries]
-    float* Pq = (float*)(Tb + AF_WAVES * 1024);                   // [waves][32 queries][AF_PQ]
-    float* red = Pq + AF_WAVES * 32 * AF_PQ;                      // [16]
-
-    const int bwh = am_xcd_order(blockIdx.x, gridDim.x);
-    const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
-    const int C = g.H * HD;
-    const int64_t rs = 3 * (int64_t)C;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r31 = lane & 31, hh = lane >> 5;
-    const int64_t lse0 = ((int64_t)bw * g.H + h) * N;
-    float* pout = part_out + (size_t)bwh * T2;
-
-    if (am_dropped(g, b)) {                  // d(out) of this sample is zero: dQ = dK = dV = 0 and no share of the table gradient
-        for (int i = tid; i < N * 4; i += blockDim.x) {
-            const int64_t t = am_token(g, b, w, i >> 2);
-            bf16* o = dqkv + t * rs + h * HD + (i & 3) * 8;
-            *(uint4*)o = make_uint4(0, 0, 0, 0);
-            *(uint4*)(o + C) = make_uint4(0, 0, 0, 0);
-            *(uint4*)(o + 2 * C) = make_uint4(0, 0, 0, 0);
-        }
-        for (int i = tid; i < T2; i += blockDim.x) pout[i] = 0.f;
-        return;
-    }
-
-    const float tau = __expf(fminf(logit_scale[h], LN100));
-    // ---- stage K^ (normalised) and V; chunk c of position n: threads 4n .. 4n+3
-    for (int c0 = tid; c0 < KR * 4; c0 += 4 * blockDim.x) {
-        U8 xk[4], xv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * blockDim.x, n = c >> 2;
-            xk[u].u = make_uint4(0, 0, 0, 0); xv[u].u = xk[u].u;
-            if (n < N) {
-                const bf16* p = qkv + am_token(g, b, w, n) * rs + C + h * HD + (c & 3) * 8;
-                xk[u].u = *(const uint4*)p;
-                xv[u].u = *(const uint4*)(p + C);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * blockDim.x, n = c >> 2;
-            float f[8], ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] = (float)xk[u].e[e]; ss += f[e] * f[e]; }
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
-            const float sc = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xk[u].e[e] = (bf16)(f[e] * sc);
-            if (n < KR) {
-                const int o = af_off(n, n < N ? n % ws : 0, c & 3);
-                *(uint4*)(Ki + o) = xk[u].u;
-                *(uint4*)(Vi + o) = xv[u].u;
-            }
-        }
-    }
-    for (int i = tid; i < T2 + 64; i += blockDim.x) tab[i] = i < T2 ? table16[(int64_t)i * g.H + h] * LOG2E : 0.f;
-    for (int i = tid; i < 64; i += blockDim.x) negrow[i] = NEG_BIG;
-    for (int i = tid; i < W2 * AF_DS; i += blockDim.x) dtab[i] = 0.f;
-
-    // ---- q-side tile of one query row: thread (px = position in the row, pc = chunk role: 0-3 q, 4-7 dO / O)
-    const int px = tid >> 3, pc = tid & 7;
-    const bool pv = px < ws;
-    struct QFetch { U8 a, o; float l; };
-    auto q_issue = [&](int qy, QFetch& f) {
-        const int n = qy * ws + min(px, ws - 1);
-        const int64_t t = am_token(g, b, w, n);
-        const bf16* pa = pc < 4 ? qkv + t * rs + h * HD + pc * 8 : dout + t * C + h * HD + (pc - 4) * 8;
-        const bf16* po = pc < 4 ? pa : outp + t * C + h * HD + (pc - 4) * 8;
-        f.a.u = *(const uint4*)pa;                                // unconditional loads on valid addresses (clamped lanes re-read a neighbour)
-        f.o.u = *(const uint4*)po;
-        f.l = lse[lse0 + n];
-    };
-    auto q_commit = [&](const QFetch& f, int buf) {
-        float x[8], acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { x[e] = (float)f.a.e[e]; acc += x[e] * (float)f.o.e[e]; }       // q: sum q^2; dO: sum dO * O
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        U8 o;
-        if (pc < 4) {
-            const float sc = pv ? tau * LOG2E / fmaxf(sqrtf(acc), 1e-12f) : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o.e[e] = (bf16)(x[e] * sc);
-            *(uint4*)(Qs + buf * 1024 + af_off(px, px, pc)) = o.u;
-            if (pc == 0) Nl[buf * 32 + px] = pv ? -f.l * LOG2E : NEG_BIG;
-        } else {
-            o.u = pv ? f.a.u : make_uint4(0, 0, 0, 0);
-            *(uint4*)(Ds + buf * 1024 + af_off(px, px, pc - 4)) = o.u;
-            if (pc == 4) Nd[buf * 32 + px] = pv ? -acc : 0.f;
-        }
-    };
-    {
-        QFetch f0;
-        q_issue(0, f0);
-        q_commit(f0, 0);
-    }
-    __syncthreads();
-
-    // ---- per-lane fragment offsets inside a 32-row image (bf16 elements)
-    const int qq = (lane & 15) >> 2, pp = lane & 3, grp = (lane >> 4) & 1;
-    int rowf[2], trq[2][2], trk[2][2];
-    auto troff = [&](int rowbase) { const int row = rowbase + qq; return af_off(row, row, 2 * grp + (pp >> 1)) + 4 * (pp & 1); };
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        rowf[s] = af_off(r31, r31, 2 * s + hh);
-        trq[s][0] = troff(16 * s + 4 * hh); trq[s][1] = troff(16 * s + 8 + 4 * hh);          // k order of an accumulator tile
-        trk[s][0] = troff(16 * s + 8 * hh); trk[s][1] = troff(16 * s + 8 * hh + 4);          // natural k order
-    }
-    const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
-    const bool wmask = MASK && am_window_masked(g, w);
-    const bool yskip = wmask && g.yskip && tau <= AM_YSKIP_TAU;
-    f32x16_t xm;                                                   // x part of the shift mask: -100 where the regions of (qx, kx) differ
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xm[r] = 0.f;
-    if (MASK && wmask) {
-        const int rk = am_rid(g, wx * ws + min(r31, ws - 1));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qx = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            xm[r] = am_rid(g, wx * ws + min(qx, ws - 1)) != rk ? -100.0f * LOG2E : 0.f;
-        }
-    }
-    const bool kpad = r31 >= ws;
-    const float* blane = tab + (ws - 1 - min(r31, ws - 1)) + 4 * hh;                            // + (dy + ws - 1) * W2 per block
-    const float* bneg = negrow + 4 * hh;
-    bf16* Tw = Tb + wave * 1024;
-    float* Pw = Pq + wave * 32 * AF_PQ;
-    const int ky0 = wave * AF_RPW;
-    const int nrow = max(0, min(AF_RPW, ws - ky0));               // key rows this wave owns (wave-uniform)
-
-    f32x16_t dk[AF_RPW], dv[AF_RPW];
-    f32x4_t R[AF_RPW];                                            // folded dS quads on their diagonal chains
-#pragma unroll
-    for (int a = 0; a < AF_RPW; ++a) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[a][r] = 0.f; dv[a][r] = 0.f; }
-        R[a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    // table gradient row dy += the four folded quads of a lane: quad gq of lane (kx', half), kx' <= ws + 2, belongs to column
-    // 8 gq + 4 half + 3 - kx' + ws - 1 (>= 0); the two halves of a register overlap in columns, so they go one after the other (LDS
-    // operations of a wave execute in order)
-    const bool fold_lane = r31 < ws + 3;
-    auto flush = [&](const f32x4_t& v, int dy) {
-        float* row = dtab + (dy + ws - 1) * AF_DS + (ws + 2 - r31) + 4 * hh;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                // one read-modify-write at a time: the columns of different quads overlap ACROSS lanes, which the compiler's per-lane view
-                // does not see (it would hoist the four loads above the four stores)
-                if (hh == half && fold_lane) row[8 * gq] += v[gq];
-                asm volatile("" ::: "memory");
-            }
-        }
-    };
-
-    float dtau_part = 0.f;
-    QFetch nf;
-    for (int qy = 0; qy < ws; ++qy) {
-        const int cur = qy & 1;
-        if (qy + 1 < ws) q_issue(qy + 1, nf);
-        const bf16* Qc = Qs + cur * 1024;
-        const bf16* Dc = Ds + cur * 1024;
-        bf16x8_t qa[2], da[2], qT[2], dT[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qa[s] = *(const bf16x8_t*)(Qc + rowf[s]);
-            da[s] = *(const bf16x8_t*)(Dc + rowf[s]);
-            qT[s] = af_tr(Qc, trq[s][0], trq[s][1]);
-            dT[s] = af_tr(Dc, trq[s][0], trq[s][1]);
-        }
-        f32x16_t nl, ndl;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4_t a4 = *(const f32x4_t*)(Nl + cur * 32 + 8 * gq + 4 * hh);
-            const f32x4_t b4 = *(const f32x4_t*)(Nd + cur * 32 + 8 * gq + 4 * hh);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { nl[4 * gq + i] = a4[i]; ndl[4 * gq + i] = b4[i]; }
-        }
-        f32x16_t dq;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-        const int rq = (MASK && wmask) ? am_rid(g, wy * ws + qy) : 0;
-        f32x4_t prev = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int a = 0; a < AF_RPW; ++a) {
-            if (a < nrow) {                                        // wave-uniform
-                const int ky = ky0 + a;
-                const int dy = qy - ky;
-                const bool ydiff = MASK && wmask && am_rid(g, wy * ws + ky) != rq;
-                f32x4_t F = {0.f, 0.f, 0.f, 0.f};
-                if (!(ydiff && yskip)) {
-                    const bf16* Kr = Ki + ky * ws * 32;
-                    const bf16* Vr = Vi + ky * ws * 32;
-                    const float* bl = kpad ? bneg : blane + (dy + ws - 1) * W2;
-                    f32x16_t sc;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) sc[4 * gq + i] = bl[8 * gq + i] + nl[4 * gq + i];
-                    if (MASK && wmask) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[r] += ydiff ? -100.0f * LOG2E : xm[r];
-                    }
-                    f32x16_t dp = ndl;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s], *(const bf16x8_t*)(Kr + rowf[s]), sc, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[s], *(const bf16x8_t*)(Vr + rowf[s]), dp, 0, 0, 0);
-                    }
-                    u32x4_t pw[2], dw[2];
-                    f32x16_t ds;
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2_t p2 = am_exp2((f32x2_t){sc[r], sc[r + 1]});
-                        const f32x2_t d2 = p2 * (f32x2_t){dp[r], dp[r + 1]};
-                        ds[r] = d2[0]; ds[r + 1] = d2[1];
-                        pw[r >> 3][(r >> 1) & 3] = am_pk(p2);
-                        dw[r >> 3][(r >> 1) & 3] = am_pk(d2);
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        dv[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dT[s], __builtin_bit_cast(bf16x8_t, pw[s]), dv[a], 0, 0, 0);
-                        dk[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[s], __builtin_bit_cast(bf16x8_t, dw[s]), dk[a], 0, 0, 0);
-                    }
-                    // dS^T through LDS: register quad gq (queries 8 gq + 4 half ..+3) of key r31 -> [key][query] image
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *(uint2*)(Tw + af_off(r31, r31, gq) + 4 * hh) = make_uint2(dw[gq >> 1][(gq & 1) * 2], dw[gq >> 1][(gq & 1) * 2 + 1]);
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_tr(Kr, trk[s][0], trk[s][1]), af_tr(Tw, trk[s][0], trk[s][1]), dq, 0, 0, 0);
-                    asm volatile("" ::: "memory");
-                    // diagonal fold of the quads: lane kx' ends up with the sum over i of ds[4 gq + i] of lane kx' - (3 - i), i.e. with the pairs
-                    // of offset dx = 8 gq + 4 half + 3 - kx'.  The values move towards the (at least three, ws <= 28) padding-key lanes behind
-                    // the row, whose own dS is exactly 0 -- they also keep the halves apart: nothing real crosses from lane 31 into lane 32
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        F[gq] = ds[4 * gq + 3] + af_shr1(ds[4 * gq + 2] + af_shr1(ds[4 * gq + 1] + af_shr1(ds[4 * gq])));
-                }
-                const f32x4_t t = R[a];
-                R[a] = prev + F;
-                prev = t;
-                if (a == nrow - 1) flush(R[a], dy);               // the chain ends at the wave's last key row
-            }
-        }
-        // ---- dQ of this query row: partial tile -> LDS (lane = query r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            *(f32x4_t*)(Pw + r31 * AF_PQ + 8 * gq + 4 * hh) = (f32x4_t){dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
-        if (qy + 1 < ws) q_commit(nf, cur ^ 1);
-        __syncthreads();
-        {
-            const int xq = wave * 8 + (lane >> 3), dc = lane & 7;  // query position in the row, dims 4 dc .. 4 dc + 3
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ww = 0; ww < AF_WAVES; ++ww) v += *(const f32x4_t*)(Pq + (ww * 32 + xq) * AF_PQ + 4 * dc);
-            const bool qv = xq < ws;
-            const int64_t t = am_token(g, b, w, qy * ws + min(xq, ws - 1));
-            U4 x;
-            x.u = *(const uint2*)(qkv + t * rs + h * HD + 4 * dc);
-            float qh[4], ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qh[e] = (float)x.e[e]; ss += qh[e] * qh[e]; }
-            ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-            const float qinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            float dot = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qh[e] *= qinv; dot += v[e] * qh[e]; }
-            if (qv) dtau_part += dot;
-            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-            dot *= tau;                                            // q^ . d(q^)
-            if (qv) {
-                U4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o.e[e] = (bf16)((tau * v[e] - qh[e] * dot) * qinv);
-                *(uint2*)(dqkv + t * rs + h * HD + 4 * dc) = o.u;
-            }
-        }
-        __syncthreads();
-    }
-    // ---- the chains still open after the last query row (dy of chain a: ws - 1 - ky)
-#pragma unroll
-    for (int a = 0; a < AF_RPW; ++a)
-        if (a < nrow - 1) flush(R[a], ws - 1 - (ky0 + a));
-    // ---- dK, dV of the wave's key rows: lane = key position r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-    for (int a = 0; a < AF_RPW; ++a) {
-        if (a < nrow) {
-            const int ky = ky0 + a;
-            const int64_t t = am_token(g, b, w, ky * ws + min(r31, ws - 1));
-            const bf16* kp = qkv + t * rs + C + h * HD + 4 * hh;
-            float kh[16], ss = 0.f;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                U4 x;
-                x.u = *(const uint2*)(kp + 8 * gq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { kh[4 * gq + e] = (float)x.e[e]; ss += kh[4 * gq + e] * kh[4 * gq + e]; }
-            }
-            ss += __shfl_xor(ss, 32, 64);
-            const float kinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            float dot = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { kh[r] *= kinv; dk[a][r] *= LN2; dot += dk[a][r] * kh[r]; }     // dk was accumulated against q~ * log2(e)
-            dot += __shfl_xor(dot, 32, 64);
-            if (!kpad) {
-                bf16* o0 = dqkv + t * rs + C + h * HD + 4 * hh;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    U4 ok, ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ok.e[e] = (bf16)((dk[a][4 * gq + e] - kh[4 * gq + e] * dot) * kinv);
-                        ov.e[e] = (bf16)dv[a][4 * gq + e];
-                    }
-                    *(uint2*)(o0 + 8 * gq) = ok.u;
-                    *(uint2*)(o0 + C + 8 * gq) = ov.u;
-                }
-            }
-        }
-    }
-    dtau_part = wave_sum(dtau_part);
-    if (lane == 0) red[wave] = dtau_part;
-    __syncthreads();
-    for (int i = tid; i < T2; i += blockDim.x) pout[i] = dtab[(i / W2) * AF_DS + i % W2];
-    if (tid == 0 && logit_scale[h] < LN100) {
-        float t = 0.f;
-        for (int i = 0; i < AF_WAVES; ++i) t += red[i];
-        atomicAdd(dlogit_scale + h, t * tau);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ launchers
 static int am_check(const char* fn, int mode, int B, int H, int hd, int N, int nW, int res, int ws, int shift) {
     MV_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "%s: mode %d", fn, mode);
@@ -2028,7 +1451,7 @@ static int am_fused_on() {
 /* 1 when mvuld_attn_bwd_mfma takes this geometry with the fused kernel: ONE call with passes = 3 then does dQ, dK, dV and the table gradient
  * (a call with passes = 2 alone is a no-op) */
 extern "C" int mvuld_attn_bwd_fused_active(int mode, int hd, int ws) {
-    return (mode == 0 && hd == 32 && ws >= 4 && ws <= 4 * AF_RPW && (ws & 3) == 0 && af_lds_bytes(ws) <= 160 * 1024 && am_fused_on()) ? 1 : 0;
+    return (mode == 0 && af_supported(hd, ws) && am_fused_on()) ? 1 : 0;
 }
 static void am_plan(AttnGeom& g, int64_t groups, int ntile, int& split, unsigned& grid) {
     static const int cus = [] {
@@ -2161,15 +1584,7 @@ extern "C" int mvuld_attn_bwd_mfma(int mode, int B, int H, int hd, int N, int nW
         const int64_t groups = (int64_t)B * nW * H;
         MV_CHECK_ARG(ws_part && ws_part_bytes >= groups * T2 * 4, "attn_bwd_mfma: the fused backward needs ws_part of %lld bytes (mvuld_attn_bwd_mfma_workspace_bytes)",
                      (long long)(groups * T2 * 4));
-        const size_t bytes = af_lds_bytes(ws);
-#define AM_FUSED(MASKV)                                                                                                  \
-    do {                                                                                                                 \
-        if (am_set_lds(attn_bwd_fused_win_k<MASKV>, bytes, "attn_bwd_fused_win_k")) return 1;                           \
-        hipLaunchKernelGGL((attn_bwd_fused_win_k<MASKV>), dim3((unsigned)groups), dim3(64 * AF_WAVES), bytes, stream, g, (const bf16*)qkv, \
-                           table16, logit_scale, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws_part, dlogit_scale);            \
-    } while (0)
-        if (shift > 0) AM_FUSED(true); else AM_FUSED(false);
-#undef AM_FUSED
+        if (af_launch(g, shift, groups, qkv, table16, logit_scale, out, dout, lse, dqkv, ws_part, dlogit_scale, stream)) return 1;
         hipLaunchKernelGGL(attn_dbias_reduce_k, dim3(cdiv(T2, 256), H, max(1, min(16, B * nW / 8))), dim3(256), 0, stream, ws_part, dtable16, T2, H,
                            B * nW, 1);
         MV_LAUNCH_CHECK("attn_bwd_mfma(fused)");
