@@ -27,10 +27,21 @@
 //     and block (qy + 1, ky + 1) share dy: the folded quads ride a 7-block diagonal chain in registers and touch the LDS table once
 //     per step instead of once per block.
 typedef float __attribute__((ext_vector_type(16))) f32x16_t;
+#ifndef AF_X
+#define AF_X 0              // timing experiments (wrong results): 1 = no blocks, 2 = no dQ slice epilogue, 3 = no q-side fetch / commit, 4 = no table-gradient fold / flush
+#endif
+#if AF_X == 9
+__device__ long long af_stamps[4][32];          // in-kernel stamps (shader cycles) of workgroup 0, step 5: cdna_hip_programming.md section 7
+#define AF_STAMP(i) do { if (blockIdx.x == 0 && qy == 5 && lane == 0) af_stamps[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mvuld_debug_af_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(af_stamps), sizeof(af_stamps)) == hipSuccess ? 0 : 1; }
+#else
+#define AF_STAMP(i) do { } while (0)
+#endif
 #define AF_RPW 7            // key rows per wave
 #define AF_WAVES 4
-#define AF_DS 60            // row stride (words) of the LDS table gradient: indices 8g + 4h - kx + ws - 1 <= 58
 #define AF_NEG 384          // words of -inf behind the bias table: a padding-key lane walks (AF_RPW - 1) table rows + 32 words of it per step
+#define AF_STG 2304         // bytes per wave: [q 8 x 64][dO 8 x 64][O 8 x 64][512 unused][lse 64 x 4]
+#define AF_NODY (-1000000)  // "no table-gradient row pending"
 #define AF_PQ 36            // row stride (words) of a dQ partial tile: 8 consecutive rows of a 16-byte store hit 32 different banks
 // [rows][32] bf16 image with 64-byte rows; the 16-byte chunk c of a row whose position inside its window row (or tile) is x sits at
 // chunk c ^ ((x >> 2) & 3): 32 consecutive rows of a 16-byte fragment read, and the 4-row blocks of a transposed read, are conflict free
@@ -53,6 +64,35 @@ __device__ __forceinline__ int64_t af_token(const AttnGeom& g, int ws, int b, in
     if (oy >= g.res) oy -= g.res;
     if (ox >= g.res) ox -= g.res;
     return ((int64_t)b * g.res + oy) * g.res + ox;
+}
+// LDS-DMA (global -> LDS, no VGPR in between), issued from inline asm so that hipcc neither counts it nor drains it: a DMA the compiler can
+// see gets s_waitcnt vmcnt(0) in front of the next LDS read it can see -- here the first fragment read of the block loop, i.e. the whole fetch
+// latency at the top of every step (what the register-staged prefetch of the first form cost once its registers were spilled: 22 % of the
+// kernel).  Lane l's 16 (4) bytes land at lds_dst + 16 l (4 l); the issuing wave waits for them itself (af_dma_wait) before it reads them.
+typedef __attribute__((address_space(3))) char* af_lds_cp;
+__device__ __forceinline__ unsigned af_lds_addr(const void* p) { return (unsigned)(uintptr_t)(af_lds_cp)(char*)p; }
+__device__ __forceinline__ void af_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void af_dma4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void af_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// sum over the 8 lanes l & ~7 .. l | 7, VALU only: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float af_sum8(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ float af_sum4(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    return v;
 }
 // whole-wave shift by one lane away from lane 0 (wave_shr:1): lane l receives lane l - 1, lane 0 receives 0
 __device__ __forceinline__ float af_shr1(float v) {
@@ -95,7 +135,8 @@ __host__ __device__ inline size_t af_lds_bytes(int ws) {
     const int N = ws * ws, W2 = 2 * ws - 1;
     return (size_t)2 * (N - ws + 32) * 64                    // K^, V images
          + (size_t)(((W2 * W2 + 64 + 3) & ~3) + AF_NEG) * 4  // bias table (log2 units) + slack behind the last row (16-byte multiple) + the -inf rows of padding keys
-         + (size_t)W2 * AF_DS * 4                            // table gradient
+         + (size_t)AF_WAVES * AF_STG                         // LDS-DMA landing zone of the next query row: per wave 8 rows of q, dO, O and their lse
+         + (size_t)2 * (32 * 32 * 2 + 32 * 4)                // raw q and 1 / |q| of two query rows (the dQ slice's normalisation backward)
          + (size_t)2 * (2 * 32 * 32 * 2 + 2 * 32 * 4)        // q-side tiles of two query rows: q~, dO, -lse, -delta
          + (size_t)AF_WAVES * 32 * 32 * 2                    // dS transposition images
          + (size_t)AF_WAVES * 32 * AF_PQ * 4                 // dQ partial tiles
@@ -120,14 +161,16 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     bf16* Vi = Ki + (size_t)KR * 32;
     float* tab = (float*)(Vi + (size_t)KR * 32);                  // [T2 + 64 (+ pad)] then negrow[64]
     float* negrow = tab + ((T2 + 64 + 3) & ~3);
-    float* dtab = negrow + AF_NEG;                                // [W2][AF_DS]
-    bf16* Qs = (bf16*)(dtab + W2 * AF_DS);                        // [2][32][32]
+    bf16* Qs = (bf16*)(negrow + AF_NEG);                          // [2][32][32]
     bf16* Ds = Qs + 2 * 1024;                                     // [2][32][32]
     float* Nl = (float*)(Ds + 2 * 1024);                          // [2][32]  -lse * log2(e)   (padding queries: -inf)
     float* Nd = Nl + 64;                                          // [2][32]  -delta
     bf16* Tb = (bf16*)(Nd + 64);                                  // [waves][32 keys][32 queries]
     float* Pq = (float*)(Tb + AF_WAVES * 1024);                   // [waves][32 queries][AF_PQ]
-    float* red = Pq + AF_WAVES * 32 * AF_PQ;                      // [16]
+    char* Stg = (char*)(Pq + AF_WAVES * 32 * AF_PQ);              // [waves][AF_STG]
+    bf16* Rq = (bf16*)(Stg + AF_WAVES * AF_STG);                  // [2][32][32] raw q, row-major 64-byte rows
+    float* Rn = (float*)(Rq + 2 * 1024);                          // [2][32] 1 / |q|
+    float* red = Rn + 64;                                         // [16]
 
     const int bwh = am_xcd_order(blockIdx.x, gridDim.x);
     const int h = bwh % g.H, bw = bwh / g.H, b = bw / g.nW, w = bw % g.nW;
@@ -150,6 +193,9 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         for (int i = tid; i < T2; i += blockDim.x) pout[i] = 0.f;
         return;
     }
+    // the table gradient of this (window, head) is summed into its own partial table with float atomics (no return value: nothing waits for
+    // them; 60 consecutive words per wave and step): zeroed here, ordered before the first atomic by the barrier behind the staging
+    for (int i = tid; i < T2; i += blockDim.x) pout[i] = 0.f;
 
     const float tau = __expf(fminf(logit_scale[h], LN100));
     const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
@@ -186,45 +232,59 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     }
     for (int i = tid; i < T2 + 64; i += blockDim.x) tab[i] = i < T2 ? table16[(int64_t)i * g.H + h] * LOG2E : 0.f;
     for (int i = tid; i < AF_NEG; i += blockDim.x) negrow[i] = NEG_BIG;
-    for (int i = tid; i < W2 * AF_DS; i += blockDim.x) dtab[i] = 0.f;
 
-    // ---- q-side tile of one query row: thread (px = position in the row, pc = chunk role: 0-3 q, 4-7 dO / O)
-    const int px = tid >> 3, pc = tid & 7;
-    const bool pv = px < ws;
-    struct QFetch { U8 a, o; float l; };
-    auto q_issue = [&](int qy, QFetch& f) {
-        const int n = qy * ws + min(px, ws - 1);
-        const int64_t t = af_token(g, ws, b, wy, wx, qy, min(px, ws - 1));
-        const bf16* pa = pc < 4 ? qkv + t * rs + h * HD + pc * 8 : dout + t * C + h * HD + (pc - 4) * 8;
-        const bf16* po = pc < 4 ? pa : outp + t * C + h * HD + (pc - 4) * 8;
-        f.a.u = *(const uint4*)pa;                                // unconditional loads on valid addresses (clamped lanes re-read a neighbour)
-        f.o.u = *(const uint4*)po;
-        f.l = lse[lse0 + n];
+    // ---- q-side tile of one query row.  Wave w fetches (LDS-DMA) and prepares rows 8 w .. 8 w + 7: lane (row = lane >> 3, pc = lane & 7), pc 0-3
+    // = the four 16-byte chunks of q, 4-7 = those of dO (and O, for delta = rowsum(dO o O))
+    // (their per-lane address arithmetic takes an OPAQUE copy of the lane index: hoisted out of the step loop it would be a dozen more
+    //  live registers, i.e. spills, and a scratch reload inside the loop shares vmcnt with the DMA)
+    char* stg = Stg + wave * AF_STG;
+    const unsigned stg_a = __builtin_amdgcn_readfirstlane(af_lds_addr(stg));
+    auto q_issue = [&](int qy) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int hh = lane >> 5;
+        // instruction 1: lanes 0-31 = (row lane >> 2, chunk lane & 3) of q, lanes 32-63 the same of dO; instruction 2: of O (both halves);
+        // instruction 3: the rows' lse (lane & 7 = row)
+        const int x1 = min(wave * 8 + ((lane & 31) >> 2), ws - 1), ch = lane & 3;
+        const int64_t t1 = af_token(g, ws, b, wy, wx, qy, x1);
+        const bf16* p1 = hh == 0 ? qkv + t1 * rs + h * HD + ch * 8 : dout + t1 * C + h * HD + ch * 8;
+        af_dma16(p1, stg_a);
+        af_dma16(outp + t1 * C + h * HD + ch * 8, stg_a + 1024);
+        af_dma4(lse + lse0 + qy * ws + min(wave * 8 + (lane & 7), ws - 1), stg_a + 2048);
     };
-    auto q_commit = [&](const QFetch& f, int buf) {
+    auto q_commit = [&](int buf) {                              // after af_dma_wait() of the issuing wave (the same wave)
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int r = lane >> 3, pc = lane & 7, px = wave * 8 + r;
+        const bool pv = px < ws;
+        U8 a, o;
+        a.u = *(const uint4*)(stg + (pc < 4 ? 0 : 512) + r * 64 + (pc & 3) * 16);
+        o.u = *(const uint4*)(stg + (pc < 4 ? 0 : 1024) + r * 64 + (pc & 3) * 16);
         float x[8], acc = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { x[e] = (float)f.a.e[e]; acc += x[e] * (float)f.o.e[e]; }       // q: sum q^2; dO: sum dO * O
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        U8 o;
+        for (int e = 0; e < 8; ++e) { x[e] = (float)a.e[e]; acc += x[e] * (float)o.e[e]; }           // q: sum q^2; dO: sum dO * O
+        acc = af_sum4(acc);
+        U8 w8;
         if (pc < 4) {
-            const float sc = pv ? tau * LOG2E / fmaxf(sqrtf(acc), 1e-12f) : 0.f;
+            const float inv = 1.0f / fmaxf(sqrtf(acc), 1e-12f);
+            const float sc = pv ? tau * LOG2E * inv : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o.e[e] = (bf16)(x[e] * sc);
-            *(uint4*)(Qs + buf * 1024 + af_off(px, px, pc)) = o.u;
-            if (pc == 0) Nl[buf * 32 + px] = pv ? -f.l * LOG2E : NEG_BIG;
+            for (int e = 0; e < 8; ++e) w8.e[e] = (bf16)(x[e] * sc);
+            *(uint4*)(Qs + buf * 1024 + af_off(px, px, pc)) = w8.u;
+            *(uint4*)(Rq + buf * 1024 + px * 32 + pc * 8) = a.u;
+            if (pc == 0) {
+                Nl[buf * 32 + px] = pv ? -((const float*)(stg + 2048))[r] * LOG2E : NEG_BIG;
+                Rn[buf * 32 + px] = inv;
+            }
         } else {
-            o.u = pv ? f.a.u : make_uint4(0, 0, 0, 0);
-            *(uint4*)(Ds + buf * 1024 + af_off(px, px, pc - 4)) = o.u;
+            w8.u = pv ? a.u : make_uint4(0, 0, 0, 0);
+            *(uint4*)(Ds + buf * 1024 + af_off(px, px, pc - 4)) = w8.u;
             if (pc == 4) Nd[buf * 32 + px] = pv ? -acc : 0.f;
         }
     };
-    {
-        QFetch f0;
-        q_issue(0, f0);
-        q_commit(f0, 0);
-    }
+    q_issue(0);
+    af_dma_wait();
+    q_commit(0);
     __syncthreads();
 
     // ---- per-lane fragment offsets inside a 32-row image (bf16 elements)
@@ -281,9 +341,9 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     }
     // table gradient row dy += the folded quads: quad gq of lane (kx', half), kx' <= ws + 2, belongs to column c = 8 gq + 4 half + 3 - kx' + ws - 1.
     // Columns of different (gq, half) overlap across lanes, so the eight pieces are first gathered per COLUMN (lane c collects its up to
-    // eight contributors with ds_bpermute: independent, one LDS latency) and the row takes ONE read-modify-write -- eight dependent
-    // read-modify-writes cost eight LDS round trips per step with nothing to hide them behind.
-    auto flush = [&](const f32x4_t& v, int dy) {
+    // eight contributors with ds_bpermute: independent, one LDS latency) and the row of the workgroup's partial table takes one float atomic
+    // per column, without return: the wave does not wait for it.
+    auto gather = [&](const f32x4_t& v) {
         float gsum = 0.f;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
@@ -293,11 +353,17 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                 const float t = __int_as_float(__builtin_amdgcn_ds_bpermute(((half << 5) | (kx & 31)) << 2, __float_as_int(v[gq])));
                 gsum += (kx >= 0 && kx < ws + 3) ? t : 0.f;
             }
-        if (lane < AF_DS) dtab[(dy + ws - 1) * AF_DS + lane] += gsum;
+        return gsum;
+    };
+    auto flush = [&](float gsum, int dy) {
+        if (lane < W2) unsafeAtomicAdd(pout + (dy + ws - 1) * W2 + lane, gsum);
     };
 
     float dtau_part = 0.f;
-    QFetch nf;
+    // the chain that ended in the previous step: gathered there, added to the partial table at the top of this step -- an atomic issued at the
+    // end of a step would still be counted in vmcnt when the step waits for its LDS-DMA (measured with in-kernel stamps: ~2 000 cycles)
+    float gpend = 0.f;
+    int dypend = AF_NODY;
     // One block = (query row qy) x (key row ky0 + a).  The seven blocks of a step run as a software pipeline -- one wave per SIMD hides no
     // latency by itself (first form of this kernel: half of all wave cycles parked in s_waitcnt, profiles/r04_fused_attn_counters.csv):
     //   L(a)  issue the LDS reads of block a: 16 bias words, two K^ and two V row fragments
@@ -309,12 +375,13 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     struct Blk { f32x16_t b; bf16x8_t kf[2], vf[2]; };
     for (int qy = 0; qy < ws; ++qy) {
         const int cur = qy & 1;
-        // raw q of this row for the dQ slice this lane finishes after the step (normalisation backward): fetched a whole step ahead
-        const int xq = wave * 8 + (lane >> 3), dc = lane & 7;      // query position in the row, dims 4 dc .. 4 dc + 3
-        const int64_t tqr = af_token(g, ws, b, wy, wx, qy, min(xq, ws - 1));
-        U4 rawq;
-        rawq.u = *(const uint2*)(qkv + tqr * rs + h * HD + 4 * dc);
-        if (qy + 1 < ws) q_issue(qy + 1, nf);
+        AF_STAMP(0);
+        int lane_e = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane_e));
+        const int xq = wave * 8 + (lane_e >> 3), dc = lane_e & 7;  // query position in the row, dims 4 dc .. 4 dc + 3
+        if (dypend > AF_NODY) flush(gpend, dypend);
+        if (qy + 1 < ws && AF_X != 3) q_issue(qy + 1);
+        AF_STAMP(1);
         const bf16* Qc = Qs + cur * 1024;
         const bf16* Dc = Ds + cur * 1024;
         bf16x8_t qa[2], da[2];
@@ -344,13 +411,14 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         // key row (the lowest address), so that every block's row is a non-negative (WS = 28: immediate) offset; padding-key lanes point into
         // the -inf words instead and walk them by the same offsets
         const float* bstep = kpad ? bneg : blane + (qy - ky0 - (nrow - 1) + ws - 1) * W2;
-        auto stage_L = [&](int a, Blk& L) {
-            const int ky = ky0 + a;
+        auto stage_Lb = [&](int a, Blk& L) {                        // the 16 bias words
             const float* bl = bstep + (nrow - 1 - a) * W2;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) L.b[4 * gq + i] = bl[8 * gq + i];
+        };
+        auto stage_Lkv = [&](int a, Blk& L) {                       // the K^ and V row fragments
 #pragma unroll
             for (int s = 0; s < 2; ++s) { L.kf[s] = *(const bf16x8_t*)(kp_row[s] + a * ws * 32); L.vf[s] = *(const bf16x8_t*)(vp_row[s] + a * ws * 32); }
         };
@@ -368,16 +436,20 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[s], L.vf[s], dp, 0, 0, 0);
             }
         };
+        AF_STAMP(2);
         Blk L[2];
         f32x16_t sc, dp;
-        if (live(0)) { stage_L(0, L[0]); stage_S(0, L[0], sc, dp); }
+#if AF_X == 1
+        if (false)
+#endif
+        if (live(0)) { stage_Lb(0, L[0]); stage_Lkv(0, L[0]); stage_S(0, L[0], sc, dp); }
         f32x4_t prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int a = 0; a < AF_RPW; ++a) {
-            if (a < nrow) {                                        // wave-uniform
+            if (a < nrow && AF_X != 1) {                                        // wave-uniform
                 const int ky = ky0 + a;
                 const bool on = live(a), on1 = a + 1 < AF_RPW && live(a + 1);
-                if (PIPE && on1) stage_L(a + 1, L[(a + 1) & 1]);
+                if (PIPE && on1) stage_Lkv(a + 1, L[(a + 1) & 1]);
                 f32x4_t F = {0.f, 0.f, 0.f, 0.f};
                 bf16x8_t k0, t0, k1, t1;
                 if (on) {
@@ -402,7 +474,7 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                     // of offset dx = 8 gq + 4 half + 3 - kx'.  The values move towards the (at least three, ws <= 28) padding-key lanes behind
                     // the row, whose own dS is exactly 0 -- they also keep the halves apart: nothing real crosses from lane 31 into lane 32
                     // (the four quads level by level: a DPP operand written by the instruction in front costs two wait states)
-                    {
+                    if (AF_X != 4) {
                         f32x4_t u;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) u[gq] = ds[4 * gq + 1] + af_shr1(ds[4 * gq]);
@@ -411,17 +483,19 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) F[gq] = ds[4 * gq + 3] + af_shr1(u[gq]);
                     }
+                    if (on1) stage_Lb(a + 1, L[(a + 1) & 1]);
                     k0 = af_trp(kp_tr[0][0] + a * ws * 32, kp_tr[0][1] + a * ws * 32); t0 = af_trp(tp_tr[0][0], tp_tr[0][1]);
                     k1 = af_trp(kp_tr[1][0] + a * ws * 32, kp_tr[1][1] + a * ws * 32); t1 = af_trp(tp_tr[1][0], tp_tr[1][1]);
                     asm volatile("" ::: "memory");
                 }
-                if (!PIPE && on1) stage_L(a + 1, L[(a + 1) & 1]);
+                if (!PIPE && on1) stage_Lkv(a + 1, L[(a + 1) & 1]);
                 if (on1) stage_S(a + 1, L[(a + 1) & 1], sc, dp);
                 if (on) af_mfma2_acc<WS == 0>(dq, k0, t0, k1, t1);
                 const f32x4_t t = R[a];
                 R[a] = prev + F;
                 prev = t;
-                if (a == nrow - 1) flush(R[a], qy - ky);          // the chain ends at the wave's last key row
+                if (a == nrow - 1 && AF_X != 4) { gpend = gather(R[a]); dypend = qy - ky; }          // the chain ends at the wave's last key row
+                AF_STAMP(3 + a);
             }
         }
         // ---- dQ of this query row: partial tile -> LDS (lane = query r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half)
@@ -429,37 +503,41 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
             *(f32x4_t*)(Pw + r31 * AF_PQ + 8 * gq + 4 * hh) = (f32x4_t){dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
-        if (qy + 1 < ws) q_commit(nf, cur ^ 1);
+        AF_STAMP(10);
+        if (qy + 1 < ws && AF_X != 3) { af_dma_wait(); q_commit(cur ^ 1); }
+        AF_STAMP(11);
         __syncthreads();
-        {
+        AF_STAMP(12);
+        if (AF_X != 2) {
             f32x4_t v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ww = 0; ww < AF_WAVES; ++ww) v += *(const f32x4_t*)(Pq + (ww * 32 + xq) * AF_PQ + 4 * dc);
             const bool qv = xq < ws;
-            float qh[4], ss = 0.f;
+            U4 rawq;
+            rawq.u = *(const uint2*)(Rq + cur * 1024 + xq * 32 + 4 * dc);     // raw q and 1 / |q| of this row: left by q_commit a step ago
+            const float qinv = Rn[cur * 32 + xq];
+            float qh[4], dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { qh[e] = (float)rawq.e[e]; ss += qh[e] * qh[e]; }
-            ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-            const float qinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-            float dot = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qh[e] *= qinv; dot += v[e] * qh[e]; }
+            for (int e = 0; e < 4; ++e) { qh[e] = (float)rawq.e[e] * qinv; dot += v[e] * qh[e]; }
             if (qv) dtau_part += dot;
-            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-            dot *= tau;                                            // q^ . d(q^)
+            dot = af_sum8(dot) * tau;                              // q^ . d(q^)
             if (qv) {
+                const int64_t tqr = af_token(g, ws, b, wy, wx, qy, xq);
                 U4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.e[e] = (bf16)((tau * v[e] - qh[e] * dot) * qinv);
                 *(uint2*)(dqkv + tqr * rs + h * HD + 4 * dc) = o.u;
             }
         }
+        AF_STAMP(13);
         __syncthreads();
+        AF_STAMP(14);
     }
     // ---- the chains still open after the last query row (dy of chain a: ws - 1 - ky)
+    if (dypend > AF_NODY) flush(gpend, dypend);
 #pragma unroll
     for (int a = 0; a < AF_RPW; ++a)
-        if (a < nrow - 1) flush(R[a], ws - 1 - (ky0 + a));
+        if (a < nrow - 1) flush(gather(R[a]), ws - 1 - (ky0 + a));
     // ---- dK, dV of the wave's key rows: lane = key position r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
     for (int a = 0; a < AF_RPW; ++a) {
@@ -502,7 +580,6 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     dtau_part = wave_sum(dtau_part);
     if (lane == 0) red[wave] = dtau_part;
     __syncthreads();
-    for (int i = tid; i < T2; i += blockDim.x) pout[i] = dtab[(i / W2) * AF_DS + i % W2];
     if (tid == 0 && logit_scale[h] < LN100) {
         float t = 0.f;
         for (int i = 0; i < AF_WAVES; ++i) t += red[i];

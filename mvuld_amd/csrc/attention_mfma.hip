@@ -1443,7 +1443,7 @@ static int am_fused_on() {
     int v = g_am_fused.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("MVULD_ATTN_BWD_FUSED");
-        v = (e && atoi(e) != 0) ? 1 : 0;          // off until it beats the three passes
+        v = (!e || atoi(e) != 0) ? 1 : 0;
         g_am_fused.store(v, std::memory_order_relaxed);
     }
     return v;
