@@ -429,12 +429,11 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] += yd ? -100.0f * LOG2E : xm[r];
             }
-            dp = ndl;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[s], L.kf[s], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[s], L.vf[s], dp, 0, 0, 0);
-            }
+            // both k-steps of S first: the exponentials of the block then run under the dP (and the previous block's dQ) products
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], L.kf[0], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], L.kf[1], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[0], L.vf[0], ndl, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[1], L.vf[1], dp, 0, 0, 0);
         };
         AF_STAMP(2);
         Blk L[2];
