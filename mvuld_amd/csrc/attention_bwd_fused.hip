@@ -129,6 +129,12 @@ __device__ __forceinline__ void af_mfma2_acc_aa(f32x16_t& acc, const u32x4_t& a0
             : "+a"(acc)
             : "a"(a0), "v"(__builtin_bit_cast(u32x4_t, b0)), "a"(a1), "v"(__builtin_bit_cast(u32x4_t, b1)));
 }
+// one k-step: acc += A.B
+template <bool SAFE>
+__device__ __forceinline__ void af_mfma1_acc_aa(f32x16_t& acc, const u32x4_t& a0, const u32x4_t& b0) {
+    if (SAFE) asm("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7" : "+a"(acc) : "a"(a0), "v"(b0));
+    else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a0), "v"(b0));
+}
 // 18+ wait states between the last MFMA that wrote the tile and whatever the compiler does with it next (v_accvgpr_read)
 __device__ __forceinline__ void af_settle(f32x16_t& acc) { asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc)); }
 __host__ __device__ inline size_t af_lds_bytes(int ws) {
@@ -373,6 +379,30 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     // in the order  L(a+1) X(a) Qi(a) S(a+1) Qm(a):  block a+1's reads fly under block a's vector work, and its score MFMAs are already in
     // the matrix pipe while the wave waits for its own dS^T to come back from LDS.
     struct Blk { f32x16_t b; bf16x8_t kf[2], vf[2]; };
+    // q-side fragments of a step: row fragments of q~ and dO (A operands of S and dP), their transposes (A operands of dK^T and dV^T, in the
+    // accumulator file), -lse and -delta per register.  Loaded right behind the barrier that publishes the row's tile -- i.e. during the
+    // previous step's dQ slice epilogue -- not at the top of the step
+    bf16x8_t qa[2], da[2];
+    u32x4_t qT[2], dT[2];
+    f32x16_t nl, ndl;
+    auto load_frags = [&](int buf) {
+        const bf16* Qc = Qs + buf * 1024;
+        const bf16* Dc = Ds + buf * 1024;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qa[s] = *(const bf16x8_t*)(Qc + rowf[s]);
+            da[s] = *(const bf16x8_t*)(Dc + rowf[s]);
+            qT[s] = __builtin_bit_cast(u32x4_t, af_tr(Qc, trq[s][0], trq[s][1]));
+            dT[s] = __builtin_bit_cast(u32x4_t, af_tr(Dc, trq[s][0], trq[s][1]));
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4_t a4 = *(const f32x4_t*)(Nl + buf * 32 + 8 * gq + 4 * hh);
+            const f32x4_t b4 = *(const f32x4_t*)(Nd + buf * 32 + 8 * gq + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { nl[4 * gq + i] = a4[i]; ndl[4 * gq + i] = b4[i]; }
+        }
+    };
     for (int qy = 0; qy < ws; ++qy) {
         const int cur = qy & 1;
         AF_STAMP(0);
@@ -382,25 +412,7 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         if (dypend > AF_NODY) flush(gpend, dypend);
         if (qy + 1 < ws && AF_X != 3) q_issue(qy + 1);
         AF_STAMP(1);
-        const bf16* Qc = Qs + cur * 1024;
-        const bf16* Dc = Ds + cur * 1024;
-        bf16x8_t qa[2], da[2];
-        u32x4_t qT[2], dT[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qa[s] = *(const bf16x8_t*)(Qc + rowf[s]);
-            da[s] = *(const bf16x8_t*)(Dc + rowf[s]);
-            qT[s] = __builtin_bit_cast(u32x4_t, af_tr(Qc, trq[s][0], trq[s][1]));
-            dT[s] = __builtin_bit_cast(u32x4_t, af_tr(Dc, trq[s][0], trq[s][1]));
-        }
-        f32x16_t nl, ndl;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4_t a4 = *(const f32x4_t*)(Nl + cur * 32 + 8 * gq + 4 * hh);
-            const f32x4_t b4 = *(const f32x4_t*)(Nd + cur * 32 + 8 * gq + 4 * hh);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { nl[4 * gq + i] = a4[i]; ndl[4 * gq + i] = b4[i]; }
-        }
+        load_frags(qy & 1);
         f32x16_t dq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -454,21 +466,25 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                 if (on) {
                     u32x4_t pw[2], dw[2];
                     f32x16_t ds;
+                    // two halves (queries 16 s .. 16 s + 15 = registers 8 s .. 8 s + 7 = k-step s of the dV^T / dK^T products): the first half's
+                    // quads go to LDS and its two MFMAs into the matrix pipe while the VALU works on the second half
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2_t p2 = am_exp2((f32x2_t){sc[r], sc[r + 1]});
-                        const f32x2_t d2 = p2 * (f32x2_t){dp[r], dp[r + 1]};
-                        ds[r] = d2[0]; ds[r + 1] = d2[1];
-                        pw[r >> 3][(r >> 1) & 3] = am_pk(p2);
-                        dw[r >> 3][(r >> 1) & 3] = am_pk(d2);
+                    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                        for (int r = 8 * s; r < 8 * s + 8; r += 2) {
+                            const f32x2_t p2 = am_exp2((f32x2_t){sc[r], sc[r + 1]});
+                            const f32x2_t d2 = p2 * (f32x2_t){dp[r], dp[r + 1]};
+                            ds[r] = d2[0]; ds[r + 1] = d2[1];
+                            pw[s][(r >> 1) & 3] = am_pk(p2);
+                            dw[s][(r >> 1) & 3] = am_pk(d2);
+                        }
+                        // dS^T through LDS: register quad gq (queries 8 gq + 4 half ..+3) of key r31 -> [key][query] image
+                        *(uint2*)tp_wr[2 * s] = make_uint2(dw[s][0], dw[s][1]);
+                        *(uint2*)tp_wr[2 * s + 1] = make_uint2(dw[s][2], dw[s][3]);
+                        af_mfma1_acc_aa<WS == 0>(dv[a], dT[s], pw[s]);
+                        af_mfma1_acc_aa<WS == 0>(dk[a], qT[s], dw[s]);
                     }
-                    // dS^T through LDS: register quad gq (queries 8 gq + 4 half ..+3) of key r31 -> [key][query] image
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *(uint2*)tp_wr[gq] = make_uint2(dw[gq >> 1][(gq & 1) * 2], dw[gq >> 1][(gq & 1) * 2 + 1]);
                     asm volatile("" ::: "memory");
-                    af_mfma2_acc_aa<WS == 0>(dv[a], dT[0], __builtin_bit_cast(bf16x8_t, pw[0]), dT[1], __builtin_bit_cast(bf16x8_t, pw[1]));
-                    af_mfma2_acc_aa<WS == 0>(dk[a], qT[0], __builtin_bit_cast(bf16x8_t, dw[0]), qT[1], __builtin_bit_cast(bf16x8_t, dw[1]));
                     // diagonal fold of the quads: lane kx' ends up with the sum over i of ds[4 gq + i] of lane kx' - (3 - i), i.e. with the pairs
                     // of offset dx = 8 gq + 4 half + 3 - kx'.  The values move towards the (at least three, ws <= 28) padding-key lanes behind
                     // the row, whose own dS is exactly 0 -- they also keep the halves apart: nothing real crosses from lane 31 into lane 32
