@@ -153,7 +153,11 @@ __host__ __device__ inline size_t af_lds_bytes(int ws) {
 // exactly AF_RPW key rows); WS = 0: any ws <= 28 with ws % 4 == 0 at run time (the small geometries of the tests)
 // PIPE: block a + 1's LDS reads are issued before block a's vector work (32 more live registers: the masked instantiation, which also holds
 // the 16 registers of the x mask, runs without it)
-template <bool MASK, int WS, bool PIPE = !MASK>
+// XM3 (WS > 0, shift == WS / 2: what SwinV2 uses): the x part of the shift mask from THREE registers instead of sixteen.  In a window of the last
+// column the positions split at s = ws - shift into two regions; a pair is masked when its query and its key lie on different sides.  For a
+// lane (one key) that is a function of the query's side only, and a register's query 8 g + 4 half + i lies on one side for both lane halves
+// except where s falls between them: m0 = the lane's addend for low queries, m1 for high ones, m2 = (half ? m1 : m0) for the straddling registers.
+template <bool MASK, int WS, bool PIPE = !MASK, bool XM3 = false>
 __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g, const bf16* __restrict__ qkv, const float* __restrict__ table16,
                                                                      const float* __restrict__ logit_scale, const bf16* __restrict__ outp,
                                                                      const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -311,13 +315,20 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     f32x16_t xm;                                                   // x part of the shift mask: -100 where the regions of (qx, kx) differ
 #pragma unroll
     for (int r = 0; r < 16; ++r) xm[r] = 0.f;
-    if (MASK && wmask) {
+    float xm3[3] = {0.f, 0.f, 0.f};
+    if (MASK && wmask && !XM3) {
         const int rk = am_rid(g, wx * ws + min(r31, ws - 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qx = (r & 3) + 8 * (r >> 2) + 4 * hh;
             xm[r] = am_rid(g, wx * ws + min(qx, ws - 1)) != rk ? -100.0f * LOG2E : 0.f;
         }
+    }
+    if (MASK && wmask && XM3 && wx == nwx - 1) {
+        const bool khigh = min(r31, ws - 1) >= ws - g.shift;
+        xm3[0] = khigh ? -100.0f * LOG2E : 0.f;
+        xm3[1] = khigh ? 0.f : -100.0f * LOG2E;
+        xm3[2] = hh ? xm3[1] : xm3[0];
     }
     const bool kpad = r31 >= ws;
     const float* blane = tab + (ws - 1 - min(r31, ws - 1)) + 4 * hh;                            // + (dy + ws - 1) * W2 per block
@@ -438,8 +449,18 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
             sc = L.b + nl;
             if (MASK && wmask) {
                 const bool yd = ydiff_of(a);
+                if constexpr (XM3) {
+                    constexpr int SX = WS / 2;                      // queries 8 g + 4 half + i >= SX are the high side
+                    const float mm[3] = {yd ? -100.0f * LOG2E : xm3[0], yd ? -100.0f * LOG2E : xm3[1], yd ? -100.0f * LOG2E : xm3[2]};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sc[r] += yd ? -100.0f * LOG2E : xm[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2);
+                        sc[r] += c >= SX ? mm[1] : (c + 4 >= SX ? mm[2] : mm[0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] += yd ? -100.0f * LOG2E : xm[r];
+                }
             }
             // both k-steps of S first: the exponentials of the block then run under the dP (and the previous block's dQ) products
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], L.kf[0], sc, 0, 0, 0);
@@ -609,17 +630,18 @@ int af_supported(int hd, int ws) { return hd == 32 && ws >= 4 && ws <= 4 * AF_RP
 int af_launch(const AttnGeom& g, int shift, int64_t groups, const void* qkv, const float* table16, const float* logit_scale, const void* out,
               const void* dout, const float* lse, void* dqkv, float* ws_part, float* dlogit_scale, hipStream_t stream) {
     const size_t bytes = af_lds_bytes(g.ws);
-#define AM_FUSED(MASKV, WSV)                                                                                                \
+#define AM_FUSED(MASKV, WSV, PIPEV, XM3V)                                                                                                \
     do {                                                                                                                 \
-        if (hipFuncSetAttribute((const void*)attn_bwd_fused_win_k<MASKV, WSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { \
+        if (hipFuncSetAttribute((const void*)attn_bwd_fused_win_k<MASKV, WSV, PIPEV, XM3V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { \
             mvuld_set_error("attn_bwd_fused_win_k: hipFuncSetAttribute(%zu) failed", bytes);                            \
             return 1;                                                                                                    \
         }                                                                                                                \
-        hipLaunchKernelGGL((attn_bwd_fused_win_k<MASKV, WSV>), dim3((unsigned)groups), dim3(64 * AF_WAVES), bytes, stream, g, (const bf16*)qkv, \
+        hipLaunchKernelGGL((attn_bwd_fused_win_k<MASKV, WSV, PIPEV, XM3V>), dim3((unsigned)groups), dim3(64 * AF_WAVES), bytes, stream, g, (const bf16*)qkv, \
                            table16, logit_scale, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, ws_part, dlogit_scale);            \
     } while (0)
-    if (g.ws == 28) { if (shift > 0) AM_FUSED(true, 28); else AM_FUSED(false, 28); }
-    else AM_FUSED(true, 0);               // the generic instantiation: masked form only (it also serves unshifted blocks)
+    if (g.ws == 28 && shift == 0) AM_FUSED(false, 28, true, false);
+    else if (g.ws == 28 && shift == 14) AM_FUSED(true, 28, true, true);
+    else AM_FUSED(true, 0, false, false); // the generic instantiation: masked form only (it also serves unshifted blocks)
 #undef AM_FUSED
     return 0;
 }
