@@ -431,14 +431,13 @@ def infer_leg(args, config, model, device, world, steps=5, warmup=2):
 
 # Kernel families of the instrumented step -> the groups `roofline` ranks.  Every attention launch (forward, the backward passes, the
 # matrix-core and the VALU forms) is ONE family, as every NT GEMM variant already is: ranking them split hid the largest time share.
-# Algorithmic FLOPs of attention: forward 4 N^2 hd, backward 10 N^2 hd per (window | sequence, head) -- what the kernels recompute on
-# top of that (scores and dP once per backward pass) is overhead, not work, so the annotated 14 N^2 hd of the three-pass backward is
-# re-priced here at 10.
+# Algorithmic FLOPs of attention: forward 4 N^2 hd, backward 10 N^2 hd per (window | sequence, head) -- what a kernel recomputes on top
+# of that (the text encoder's two-pass backward forms the scores and dP twice) is overhead, not work.
 FAMILY_GROUPS = {
     "attention": ("attn_fwd_mfma", "attn_bwd_mfma", "attn_fwd_simple", "attn_bwd_simple"),
     "gemm_nt_mfma_bf16": ("gemm_nt_mfma_bf16", "gemm_nt_mfma_fp8"),
 }
-FLOP_REPRICE = {"attn_bwd_mfma": 10.0 / 14.0}
+FLOP_REPRICE = {}
 TRAFFIC_KERNELS = {
     "attention": ("attn_fwd_win_k", "attn_fwd_mfma_k", "attn_bwd_dq_mfma_k", "attn_bwd_dkv_mfma_k", "attn_bwd_dbias_mfma_k", "attn_dbias_reduce_k",
                   "attn_bwd_fused_win_k"),

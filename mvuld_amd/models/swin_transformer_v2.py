@@ -156,8 +156,9 @@ class _SwinBlockFn(torch.autograd.Function):
         # zeroed accumulators of the two passes that run on the weight-gradient stream (bias-table gradient, q/v-bias column sums):
         # ONE fill, issued on that stream -- not on the critical chain of data-gradient kernels
         wgs = ops.wgrad_stream_for_current()
-        if wgs is not None and not ops._mfma_attn_ok(geom, qkv.dtype):
-            wgs = None                            # the VALU attention backward accumulates the table gradient on THIS stream
+        if wgs is not None and (not ops._mfma_attn_ok(geom, qkv.dtype) or ops.attn_bwd_is_fused(geom)):
+            wgs = None                            # the VALU and the fused attention backward accumulate the table gradient on THIS stream
+                                                  # (the q/v-bias column sums on the weight-gradient stream are ordered behind dqkv, hence behind this fill)
         with torch.cuda.stream(wgs if wgs is not None else torch.cuda.current_stream(x.device)):
             zbuf = torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
         dtable = zbuf[:T2 * H].view(T2, H)

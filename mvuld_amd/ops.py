@@ -953,6 +953,12 @@ USE_DROPPATH_SKIP = [os.environ.get("MVULD_DROPPATH_SKIP", "1") != "0"]
 BIAS_STREAM = [None]       # stream on which the last attn_bwd left dtable16 (None = the current one)
 
 
+def attn_bwd_is_fused(g: AttnGeom) -> bool:
+    """True when mvuld_attn_bwd_mfma takes this geometry with the fused single-pass kernel (dQ, dK, dV and the table gradient on the
+    caller's stream, in one call)."""
+    return g.mode == 0 and hip.LIB.fn("mvuld_attn_bwd_fused_active")(0, g.hd, g.ws) == 1
+
+
 def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, valid=None, dtable16=None, dlogit_scale=None, sample_scale=None):
     dqkv = torch.empty_like(qkv)
     ss = ptr(sample_scale) if USE_DROPPATH_SKIP[0] else None
@@ -960,12 +966,12 @@ def attn_bwd(g: AttnGeom, qkv, out, dout, lse, table16=None, logit_scale=None, v
     if _mfma_attn_ok(g, qkv.dtype):
         delta = torch.empty((qkv.shape[0] * g.H,), dtype=torch.float32, device=qkv.device)
         qt = torch.empty((qkv.shape[0], g.H * g.hd), dtype=torch.bfloat16, device=qkv.device) if g.mode == 0 else None
-        hip.TIMING.annotate("attn_bwd_mfma", 14.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)
+        hip.TIMING.annotate("attn_bwd_mfma", 10.0 * (g.sumsq if g.mode == 2 else g.N * g.N * g.B * g.nW) * g.hd * g.H)      # algorithmic: five products
         args = (*g.args(), ptr(qkv), ptr(table16), ptr(logit_scale), ptr(valid), ptr(out), ptr(dout), ptr(lse),
                 ptr(dqkv), ptr(dtable16), ptr(dlogit_scale), ptr(delta), ptr(qt))
         wg = wgrad_stream_for_current() if g.mode == 0 else None
         # round 4: the fused window backward forms the table gradient in the same pass as dQ / dK / dV -- one call, this stream
-        fused = g.mode == 0 and hip.LIB.fn("mvuld_attn_bwd_fused_active")(0, g.hd, g.ws) == 1
+        fused = attn_bwd_is_fused(g)
         if g.mode != 0 or wg is None or fused:
             part = _workspace(qkv.device, hip.LIB.fn("mvuld_attn_bwd_mfma_workspace_bytes")(0, g.B, g.H, g.nW, g.ws)) if g.mode == 0 else None
             call("attn_bwd_mfma", *args, ptr(part), part.numel() * 4 if part is not None else 0, 3, g.drop_p, g.drop_seed,

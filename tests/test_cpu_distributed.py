@@ -117,6 +117,47 @@ def _worker_wiring(rank, world, port, out):
         open(out, "w").write("ok")
 
 
+def _worker_bf16(rank, world, port, out):
+    """the bf16-payload exchange (north_star's 464 MB) equals the fp32 exchange to bf16 rounding."""
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mvuld_amd.distributed import GradAllReducer, init_distributed
+    init_distributed(backend="gloo")
+    n = 300_001
+    gen = torch.Generator().manual_seed(7 + rank)
+    base = torch.randn(n, generator=gen) * torch.logspace(-6, 2, n)          # eight decades of gradient magnitudes
+    got = {}
+    for payload in ("fp32", "bf16"):
+        g = base.clone()
+        red = GradAllReducer(g, max_bucket_elems=1 << 16, payload=payload)
+        red.launch_ranges([(1000, 70_000), (200_000, n)])                     # "from inside backward"
+        red.finish()                                                          # the rest, then wait (and widen)
+        got[payload] = g
+    parts = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(parts, base)
+    want = sum(parts)
+    assert torch.equal(got["fp32"], want)
+    # each rank's contribution rounded to bf16 (unit roundoff 2^-8) and one bf16 addition (2^-8 of the sum): |error| <= ~2^-7 (|a| + |b|)
+    bound = (parts[0].abs() + parts[1].abs()) * 2.0 ** -7 * 1.01 + 1e-30
+    assert bool(((got["bf16"] - want).abs() <= bound).all()), float(((got["bf16"] - want).abs() / bound).max())
+    assert float((got["bf16"] - want).abs().max()) > 0.0                      # ... and it really went through bf16
+    all_b = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(all_b, got["bf16"])
+    assert torch.equal(all_b[0], all_b[1])                                    # every rank ends with the same bits
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        open(out, "w").write("ok")
+
+
+def test_bf16_payload_gradient_exchange_gloo_world2(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker_bf16, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_bench_data_parallel_wiring_gloo_world2(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_worker_wiring, args=(2, _free_port(), out), nprocs=2, join=True)
