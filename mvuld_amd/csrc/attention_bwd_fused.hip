@@ -420,10 +420,10 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         int lane_e = threadIdx.x & 63;
         asm volatile("" : "+v"(lane_e));
         const int xq = wave * 8 + (lane_e >> 3), dc = lane_e & 7;  // query position in the row, dims 4 dc .. 4 dc + 3
+        load_frags(qy & 1);                                       // (their LDS latency passes under the address arithmetic of the fetch below)
         if (dypend > AF_NODY) flush(gpend, dypend);
         if (qy + 1 < ws && AF_X != 3) q_issue(qy + 1);
         AF_STAMP(1);
-        load_frags(qy & 1);
         f32x16_t dq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[r] = 0.f;

@@ -42,13 +42,20 @@ def step():
     mark("fwd head done")
     loss.backward()
     mark("bwd returned (main)")
+    # where the other streams stand once the host has enqueued the whole backward (events on THOSE streams; un-traced)
+    for nm, st in (("weight-gradient stream drained", getattr(model, "_wg", None)), ("text stream drained", getattr(model, "_side", None)),
+                   ("graph stream drained", getattr(model, "_gs", None))):
+        if st is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            marks[nm] = e
     opt.clip_grad_norm_(config.TRAIN.CLIP_GRAD)
     opt.step()
     opt.zero_grad()
     mark("step done")
 
 
-for _ in range(3):
+for _ in range(4):
     step()
 torch.cuda.synchronize()
 base = marks["start"]
