@@ -506,6 +506,13 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                         af_mfma1_acc_aa<WS == 0>(dk[a], qT[s], dw[s]);
                     }
                     asm volatile("" ::: "memory");
+                    // every LDS request of the block's tail goes out NOW, in one burst: the transposed reads of dS^T (behind the quads' stores: the
+                    // LDS executes a wave's operations in order) and of K^T, and block a + 1's bias words; the diagonal fold below (16 dependent
+                    // DPP instructions, no memory) covers their latency.  Left to hipcc the transposed reads sit directly in front of their wait.
+                    k0 = af_trp(kp_tr[0][0] + a * ws * 32, kp_tr[0][1] + a * ws * 32); t0 = af_trp(tp_tr[0][0], tp_tr[0][1]);
+                    k1 = af_trp(kp_tr[1][0] + a * ws * 32, kp_tr[1][1] + a * ws * 32); t1 = af_trp(tp_tr[1][0], tp_tr[1][1]);
+                    if (on1) stage_Lb(a + 1, L[(a + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                     // diagonal fold of the quads: lane kx' ends up with the sum over i of ds[4 gq + i] of lane kx' - (3 - i), i.e. with the pairs
                     // of offset dx = 8 gq + 4 half + 3 - kx'.  The values move towards the (at least three, ws <= 28) padding-key lanes behind
                     // the row, whose own dS is exactly 0 -- they also keep the halves apart: nothing real crosses from lane 31 into lane 32
@@ -519,10 +526,7 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) F[gq] = ds[4 * gq + 3] + af_shr1(u[gq]);
                     }
-                    if (on1) stage_Lb(a + 1, L[(a + 1) & 1]);
-                    k0 = af_trp(kp_tr[0][0] + a * ws * 32, kp_tr[0][1] + a * ws * 32); t0 = af_trp(tp_tr[0][0], tp_tr[0][1]);
-                    k1 = af_trp(kp_tr[1][0] + a * ws * 32, kp_tr[1][1] + a * ws * 32); t1 = af_trp(tp_tr[1][0], tp_tr[1][1]);
-                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!PIPE && on1) stage_Lkv(a + 1, L[(a + 1) & 1]);
                 if (on1) stage_S(a + 1, L[(a + 1) & 1], sc, dp);
