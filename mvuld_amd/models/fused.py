@@ -84,6 +84,8 @@ class FusedMVulD(nn.Module):
             self.unixcoder.eval()                                      # offline feature extraction semantics: no dropout, no gradient
             g.ndata["_UNIX_NODE_EMB"] = self.unixcoder.encode_lines(node_ids, node_lens).float()
             self.unixcoder.train(was)
+        if torch.is_grad_enabled() and self.training:
+            ops.ZERO_POOL.begin_step()
         if not concurrent:
             ops.WGRAD_STREAM[0] = None
             ops.on_backward_done("unixcoder", None, key="fused-join")

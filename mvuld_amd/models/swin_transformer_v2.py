@@ -160,7 +160,8 @@ class _SwinBlockFn(torch.autograd.Function):
             wgs = None                            # the VALU and the fused attention backward accumulate the table gradient on THIS stream
                                                   # (the q/v-bias column sums on the weight-gradient stream are ordered behind dqkv, hence behind this fill)
         with torch.cuda.stream(wgs if wgs is not None else torch.cuda.current_stream(x.device)):
-            zbuf = torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
+            # (one buffer and one fill per step for all blocks when the fused model armed the pool; own torch.zeros otherwise)
+            zbuf = ops.ZERO_POOL.take(T2 * H + 3 * C, x.device) if wgs is None else torch.zeros(T2 * H + 3 * C, dtype=torch.float32, device=x.device)
         dtable = zbuf[:T2 * H].view(T2, H)
         dqkv = ops.attn_bwd(geom, qkv, att, datt, lse, table16, a.logit_scale.data.view(-1), None, dtable,
                             ops.grad_of(a.logit_scale).view(-1), sample_scale=rs_a)
@@ -177,9 +178,16 @@ class _SwinBlockFn(torch.autograd.Function):
             # [3C] scratch, two slice adds) instead of two more passes over dqkv
             dqb = zbuf[T2 * H:]
             st = ops.linear_wgrad(dqkv, x, a.qkv.weight, None, bias_out=dqb)
-            with torch.cuda.stream(st):                                 # the stream of the kernel that filled dqb
-                ops.grad_of(a.q_bias).add_(dqb[:C])
-                ops.grad_of(a.v_bias).add_(dqb[2 * C:])
+            # grad(q_bias) += dqb[:C], grad(v_bias) += dqb[2C:]: two jobs of the stage's batched reduction launch (columns [0, C) of
+            # dqb into the "low" destination, columns [C, 2C) of dqb + C into the "high" one) instead of two aten adds per block
+            # (only while the fused step's weight-gradient stream is active: its fire_backward_done flushes the deferred launches)
+            if ops.wgrad_stream_for_current() is not None:
+                ops.defer_column_add(dqb, dst_lo=ops.grad_of(a.q_bias), dst_hi=None, C=C, src_stream=st)
+                ops.defer_column_add(dqb[C:], dst_lo=None, dst_hi=ops.grad_of(a.v_bias), C=C, src_stream=st)
+            else:
+                with torch.cuda.stream(st):                             # the stream of the kernel that filled dqb
+                    ops.grad_of(a.q_bias).add_(dqb[:C])
+                    ops.grad_of(a.v_bias).add_(dqb[2 * C:])
         else:
             ops.linear_wgrad(dqkv, x, a.qkv.weight, None)
         dx = ops.gemm_nt(dqkv, ops.weight_t(a.qkv.weight, ad), epi=hip.EPI_ADD_AUX, aux=g1)

@@ -55,6 +55,43 @@ def fire_backward_done(tag):
         WGRAD_STREAM[0] = None            # the step's backward is over: later launches (other models, tests) stay on their own stream
 
 
+class _ZeroPool:
+    """Zeroed fp32 scratch of one training step's backward, carved from ONE buffer that one fill clears: the 24 Swin blocks each took
+    their own torch.zeros before (table-gradient accumulator + q/v-bias column sums: 24 fills per step on the backward chain).
+    `begin_step()` (the fused model's forward) retires the previous buffer and sizes the next one from what the last backward took;
+    the first take() of a backward allocates and clears it on the CURRENT stream -- every later user, on any stream, is ordered behind
+    kernels of this stream.  Without begin_step() (stand-alone modules, tests) every take() is its own torch.zeros, as before."""
+
+    def __init__(self):
+        self.buf, self.off, self.took, self.size, self.armed = None, 0, 0, 0, False
+
+    def begin_step(self):
+        self.size = max(self.size, self.took)
+        self.buf, self.off, self.took, self.armed = None, 0, 0, True
+
+    def take(self, n, device):
+        n64 = (n + 63) // 64 * 64
+        self.took += n64
+        if self.armed and self.buf is None and self.size >= n64:
+            self.buf, self.off = torch.zeros(self.size, dtype=torch.float32, device=device), 0
+        if self.buf is not None and self.buf.device == device and self.off + n64 <= self.buf.numel():
+            out = self.buf[self.off:self.off + n]
+            self.off += n64
+            return out
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+ZERO_POOL = _ZeroPool()
+
+
+def defer_column_add(src, dst_lo=None, dst_hi=None, C=None, src_stream=None):
+    """dst_lo += src[:C], dst_hi += src[C:2C] (fp32 vectors), deferred into the next batched reduction launch (ln_reduce_flush: it takes
+    [nparts][2C] column partials, here nparts = 1) instead of one aten add_ per vector.  `src_stream`: the stream `src` was produced on (what linear_wgrad returns)."""
+    if src_stream is None:
+        src_stream = torch.cuda.current_stream(src.device)
+    _LN_PENDING.append((src, 1, C, dst_lo, dst_hi, src_stream))
+
+
 def bump_weight_epoch():
     WEIGHT_EPOCH[0] += 1
 
@@ -554,7 +591,7 @@ def ln_reduce_flush():
             part.record_stream(dst)
     desc = (ctypes.c_int64 * (5 * len(lns)))()
     for k, (part, nparts, C, dg, db, src) in enumerate(lns):
-        desc[5 * k:5 * k + 5] = [part.data_ptr(), nparts, C, dg.data_ptr(), db.data_ptr()]
+        desc[5 * k:5 * k + 5] = [part.data_ptr(), nparts, C, dg.data_ptr() if dg is not None else 0, db.data_ptr() if db is not None else 0]
     with torch.cuda.stream(dst):
         call("layernorm_bwd_reduce_batch", ctypes.addressof(desc), len(lns))
 
