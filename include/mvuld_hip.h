@@ -63,10 +63,6 @@ int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA, const floa
                         int64_t strideC, int M, int N, int K, int batch, const float* bias, int epilogue, float* aux, int64_t ldaux,
                         int64_t strideAux, float alpha, int out_mode, int trans_a, int trans_b, int splitk, mvuld_stream_t stream);
 
-/* Opt-in for the experimental 256 x 256-tile, 4-stage LDS-DMA ring variant of mvuld_gemm_nt: products with K >= min_k
- * (K % 32 == 0, >= 128 tiles, plain store) take it; 0 (default) = never.  No stream argument: host-side setting. */
-int mvuld_set_gemm_256_min_k(int min_k);
-
 /* fp8 forward GEMMs (BASELINE configs[4]: "fp8 (CDNA4 MFMA) QKV/FFN GEMMs in SwinV2 + UniXcoder"; same call sites as mvuld_gemm_nt:
  * swin_transformer_v2.py:146-152,177,26-32 and the RobertaModel dense layers behind unixcoder.py:36).
  * mvuld_quant_e4m3: per-tensor quantisation to OCP e4m3 (gfx950's native fp8): scale_out[0] = max|x| / 448, out = e4m3(x / scale);
@@ -113,11 +109,6 @@ int mvuld_set_gemm_p256_pingpong(int on);
  * per LDS-DMA instruction; 2 stages, 3 at <= 160-row tiles), 0 = 32-deep stages (16 rows x 64 bytes per instruction, 4 stages).
  * Bit-identical results; initialised from MVULD_P256_K64. */
 int mvuld_set_gemm_p256_k64(int on);
-/* Full-line ring only: 1 = every wave issues the next tile's last prefetched step BEFORE its epilogue's stores (vmcnt retires in issue
- * order: the stores then never sit in front of a load that is waited for within the tile's first steps), 0 = after them.
- * Bit-identical results; initialised from MVULD_P256_EARLY. */
-int mvuld_set_gemm_p256_early(int on);
-
 /* Fused MLP of the narrow Swin stages (Mlp.forward, swin_transformer_v2.py:26-32, and its autograd), C = 128 / 256, bf16, hidden = 4C:
  * at these widths the MLP's products are HBM streams; these two kernels keep the hidden dimension on the chip (csrc/mlp_panel.hip).
  *   fwd: y [M, C] = gelu(x W1^T + b1) W2^T + b2 and the activation h [M, 4C] (the fc2 weight gradient reads it; null = not
@@ -233,10 +224,6 @@ int mvuld_attn_bwd_simple(int mode, int B, int H, int hd, int N, int nW, int res
  * the backward passes from the same seed.  p = 0 switches it off. */
 /* mode 2 (matrix-core kernels only): mode 1 over PACKED sequences: `valid` carries cu [B+1], N = the longest sequence allowed
  * (sizes LDS and the lse rows: lse is [B, H, N]), `res` = total packed tokens; every packed token is a valid key. */
-/* forward / dQ / dK,dV passes: when the (window x head) groups do not fill whole rounds of the CUs (the text encoder's 32 x 12 = 384
- * on 256), the groups of the partial last round are split over 2..4 workgroups each so that it fills up (results are bit-identical:
- * a query / key tile is computed by one wave either way).  1 = on, 0 = off (default; MVULD_ATTN_TAIL_SPLIT) -- measured neutral */
-int mvuld_set_attn_tail_split(int on);
 /* mode 0, head_dim 32, window side a multiple of 4 (the SwinV2 stages with 28 x 28 windows): the FORWARD pass runs on the window fast
  * path (three shifted copies of the bias table read with aligned 8-byte LDS reads, two query tiles per wave).  1 (default) = with the
  * deferred softmax maximum (the running maximum of a query moves only when a block exceeds it by 2^6; out / lse equal the general

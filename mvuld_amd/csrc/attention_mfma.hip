@@ -1387,12 +1387,9 @@ static int am_split(int64_t groups, int ntile) {
     return s;
 }
 
-// Workgroups of the forward / dQ / dK,dV passes: (window x head) groups that do not fill whole rounds of the chip (the text encoder's
-// 32 x 12 = 384 on 256 CUs: a second round half empty) leave the groups of the last, partial round split `f` ways so that it fills
-// up too -- 256 whole + 128 x 2 halves = 1.5 rounds of work in 1.5 rounds of time; the split ones stage their K/V (or Q~/dO) tile f times.
-// MVULD_ATTN_TAIL_SPLIT / mvuld_set_attn_tail_split: 1 = balance the last round, 0 = off (default).  Measured on the text encoder's 384
-// groups: forward 73.3 vs 73.8 us, backward 177.9 vs 179.9 us, whole step 60.4 vs 60.2 ms -- re-staging K/V for the halves costs what the
-// emptier round saved, and beside other streams the half-empty round was never idle.  Bit-identical either way (tests).
+// (Round 3 measured a "tail split" of the partial last round of (window x head) groups -- the text encoder's 384 groups on 256 CUs -- neutral:
+// forward 73.3 vs 73.8 us, backward 177.9 vs 179.9 us, step 60.4 vs 60.2 ms; its knob left the library in round 4, the `whole` field of
+// AttnGeom and am_part's handling of it remain for the record: tools/experiments/README.md.)
 // Skipping of the tiles across a shifted window's vertical mask split (am_ysplit): MVULD_ATTN_YSKIP / mvuld_set_attn_yskip, 1 = on (default),
 // 0 = every pair is computed.  Bit-identical either way while tau <= 22 (tests); a head past that bound computes every pair regardless.
 static std::atomic<int> g_am_yskip{-1};
@@ -1408,11 +1405,6 @@ static int am_yskip_on() {
         g_am_yskip.store(v, std::memory_order_relaxed);
     }
     return v;
-}
-static std::atomic<int> g_am_tail{-1};
-extern "C" int mvuld_set_attn_tail_split(int on) {
-    g_am_tail.store(on ? 1 : 0, std::memory_order_relaxed);
-    return 0;
 }
 // Forward window fast path (attn_fwd_win_k) for MODE 0, head_dim 32, window side % 4 == 0.  MVULD_ATTN_WIN / mvuld_set_attn_win:
 // 1 (default) = fast path with the deferred maximum, 2 = fast path on the general kernel's exact schedule (bit-identical to it: test),
@@ -1454,27 +1446,9 @@ extern "C" int mvuld_attn_bwd_fused_active(int mode, int hd, int ws) {
     return (mode == 0 && af_supported(hd, ws) && am_fused_on()) ? 1 : 0;
 }
 static void am_plan(AttnGeom& g, int64_t groups, int ntile, int& split, unsigned& grid) {
-    static const int cus = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        return v > 0 ? v : 256;
-    }();
-    int tail = g_am_tail.load(std::memory_order_relaxed);
-    if (tail < 0) {
-        const char* e = getenv("MVULD_ATTN_TAIL_SPLIT");
-        tail = e ? (atoi(e) ? 1 : 0) : 0;
-        g_am_tail.store(tail, std::memory_order_relaxed);
-    }
     split = am_split(groups, ntile);
     g.whole = 0;
     grid = (unsigned)(groups * split);
-    const int rem = (int)(groups % cus);
-    if (tail && split == 1 && groups > cus && groups < 4 * (int64_t)cus && rem > 0) {
-        int f = cus / rem;
-        if (f > 4) f = 4;
-        while (f >= 2 && f * 16 > ntile * 2) --f;            // every part keeps at least half a tile round of its 16 waves
-        if (f >= 2) { g.whole = (int)(groups - rem); split = f; grid = (unsigned)(g.whole + rem * f); }
-    }
 }
 
 #define AM_LAUNCH(KERNEL, HDV, MODEV, bytes, ...)                                                \

@@ -372,186 +372,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void gemm_nt_mfma_bf16(Gemm
 // function of the row group so that every 16-lane group of a ds_read_b128 fragment read covers all 64 banks
 __device__ __forceinline__ int g2_off(int row, int ch) { return row * 64 + ((ch ^ ((4 - ((row >> 2) & 3)) & 3)) << 4); }
 
-template <typename TO>
-__global__ __launch_bounds__(512, 1) void gemm_nt_mfma_bf16_256(GemmArgs g, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef __attribute__((address_space(1))) const void* glb_vp;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nt = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nt >> 3, r = nt & 7, x = bid & 7, i = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
-    const int b = blockIdx.y;
-    const bf16* A = (const bf16*)g.A + (int64_t)b * g.sA;
-    const bf16* B = (const bf16*)g.B + (int64_t)b * g.sB;
-    TO* C = (TO*)g.C + (int64_t)b * g.sC;
-    TO* aux = g.aux ? (TO*)g.aux + (int64_t)b * g.sAux : nullptr;
-    const int nk = g.K / G2_BK;
-
-    // LDS-DMA map: one instruction fills 1 KiB = 16 tile rows in lane order (lane l -> row l >> 2, slot l & 3), so the lane fetches
-    // the chunk that the swizzle stores in its slot.  Wave w issues pieces 2w, 2w+1 of the A tile and of the B tile.
-    const bf16* ga[2];
-    const bf16* gb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
-        const int ch = (lane & 3) ^ ((4 - ((row >> 2) & 3)) & 3);
-        ga[i] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + ch * 8;
-        gb[i] = B + (int64_t)min(n0 + row, g.N - 1) * g.ldb + ch * 8;
-    }
-    auto issue = [&](int kt) {
-        char* st = smem + (kt & 3) * G2_STAGE_BYTES;
-        const int k0 = kt * G2_BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_vp)(ga[i] + k0), (lds_vp)(st + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(gb[i] + k0), (lds_vp)(st + 16384 + (wave * 2 + i) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // fragment byte offsets inside a stage (constant over the loop)
-    int oa[8], ob[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) oa[i] = g2_off(wr * 128 + i * 16 + fr, fg);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ob[i] = 16384 + g2_off(wc * 64 + i * 16 + fr, fg);
-
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-        if (s < nk) issue(s);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the two younger tiles (4 loads each) are still in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // everyone's pieces of tile kt are visible; everyone is done with tile kt-1
-        if (kt + 3 < nk) issue(kt + 3);          // refills the stage tile kt-1 occupied
-        const char* st = smem + (kt & 3) * G2_STAGE_BYTES;
-        bf16x8_t fa[8], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fb[i] = *(const bf16x8_t*)(st + ob[i]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8_t*)(st + oa[i]);
-        // all 12 fragment reads issue before the first MFMA (else hipcc reads one, waits, multiplies).  Prefetching the next
-        // tile's fragments into a second register set was tried: 250 VGPRs, the allocator starts shuffling accumulators (127
-        // v_mov per two steps) and the kernel gets slower; the LDS latency is covered by the SIMD's other wave instead.
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-
-    // ---- epilogue: four 32-row quarters of the wave's 128 x 64 block through a per-wave fp32 LDS tile, then 16-byte row stores
-    float* ep = (float*)(smem + wave * (32 * GT_EPI_LD * 4));
-    const int lc = (lane & 7) * 8;
-    const int col = n0 + wc * 64 + lc;
-    const bool vec_ok = (g.out_mode == OUT_STORE) && (g.N % 8 == 0) && (g.ldc % 8 == 0) && (g.epi < EPI_GELU || (g.ldaux % 8 == 0));
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float t = g.bias[min(col + e, g.N - 1)];
-            bias8[e] = (col + e < g.N) ? t : 0.f;
-        }
-    }
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(i * 16 + fg * 4 + r) * GT_EPI_LD + j * 16 + fr] = acc[qt * 2 + i][j][r];
-        __syncthreads();
-#pragma unroll 2
-        for (int p = 0; p < 4; ++p) {
-            const int lr = p * 8 + (lane >> 3);
-            const int row = m0 + wr * 128 + qt * 32 + lr;
-            const bool valid = row < g.M && col < g.N;
-            const float4 va = *(const float4*)(ep + lr * GT_EPI_LD + lc);
-            const float4 vb = *(const float4*)(ep + lr * GT_EPI_LD + lc + 4);
-            float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-            if (vec_ok) {
-                float ax[8];
-                if (epi_reads_aux(g.epi)) {
-                    const TO* ap = aux + (int64_t)min(row, g.M - 1) * g.ldaux + (col < g.N ? col : 0);
-                    if constexpr (sizeof(TO) == 4) {
-                        const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
-                        ax[0] = a0.x; ax[1] = a0.y; ax[2] = a0.z; ax[3] = a0.w; ax[4] = a1.x; ax[5] = a1.y; ax[6] = a1.z; ax[7] = a1.w;
-                    } else {
-                        const bf16x8 a = *(const bf16x8*)ap;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ax[e] = (float)a.v[e];
-                    }
-                }
-                float pre[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = g.alpha * v[e] + bias8[e];
-                    pre[e] = x;
-                    switch (g.epi) {
-                        case EPI_GELU: x = gelu_t<TO>(x); break;
-                        case EPI_GELU_DG: gelu_dgelu_t<TO>(x, x, pre[e]); break;      // aux <- gelu'(pre-activation)
-                        case EPI_MUL_AUX: x *= ax[e]; break;
-                        case EPI_ELU: x = elu1(x); break;
-                        case EPI_MUL_DGELU: x *= dgelu_t<TO>(ax[e]); break;
-                        case EPI_MUL_DELU: x *= (ax[e] > 0.f ? 1.0f : ax[e] + 1.0f); break;
-                        case EPI_ADD_AUX: x += ax[e]; break;
-                        default: break;
-                    }
-                    v[e] = x;
-                }
-                if (!valid) continue;
-                TO* cp = C + (int64_t)row * g.ldc + col;
-                if constexpr (sizeof(TO) == 4) {
-                    *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-                    *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    if (epi_writes_aux(g.epi) && aux) {
-                        float* qp = (float*)(aux + (int64_t)row * g.ldaux + col);
-                        *(float4*)qp = make_float4(pre[0], pre[1], pre[2], pre[3]);
-                        *(float4*)(qp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
-                    }
-                } else {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o.v[e] = (bf16)v[e];
-                    *(bf16x8*)cp = o;
-                    if (epi_writes_aux(g.epi) && aux) {
-                        bf16x8 q;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) q.v[e] = (bf16)pre[e];
-                        *(bf16x8*)(aux + (int64_t)row * g.ldaux + col) = q;
-                    }
-                }
-            } else if (valid) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (col + e < g.N) epilogue_store<TO>(g, C, aux, row, col + e, v[e]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------ MFMA bf16, 128 x 128 tile, 3-stage LDS-DMA ring
+// (The opt-in 256 x 256 ring kernel that stood here -- gemm_nt_mfma_bf16_256, 1.09 PFLOP/s at 4096^3 but one workgroup per CU -- lost to the
+// persistent kernel of gemm_p256.hip on every shape of the step and left the library in round 4: tools/experiments/gemm_nt_mfma_bf16_256.hip.txt.)
 // The ring structure of gemm_nt_mfma_bf16_256 at the small tile: 4 waves x (64 x 64), three 32-deep stages of 16 KiB (48 KiB:
 // 3 workgroups / CU like the default kernel), two tiles in flight per workgroup at all times, one barrier per k-step, no VGPR
 // staging and no ds_write.  Meant for the short-K shapes where the default loop's single burst of loads per k-step leaves the
@@ -1350,13 +1172,6 @@ extern "C" int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA,
 }
 
 // ------------------------------------------------------------------------------------ C ABI
-static std::atomic<int> g_k256{-1};     // minimum K for the 256 x 256 ring kernel (0 = never); -1 = read MVULD_GEMM_256 on first use
-
-extern "C" int mvuld_set_gemm_256_min_k(int min_k) {
-    g_k256.store(min_k < 0 ? 0 : min_k, std::memory_order_relaxed);
-    return 0;
-}
-
 extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                              void* C, int64_t ldc, int64_t strideC, int M, int N, int K, int batch,
                              const float* bias, int epilogue, void* aux, int64_t ldaux, int64_t strideAux,
@@ -1382,28 +1197,6 @@ extern "C" int mvuld_gemm_nt(const void* A, int64_t lda, int64_t strideA, const 
     if (use_mfma) {
         // persistent 256 x 256 kernel (gemm_p256.hip): the tall bf16 -> bf16 products of the two encoders
         if (mvuld_gemm_nt_p256_try(g, dtype_out, stream) == 0) { MV_LAUNCH_CHECK("gemm_nt_bf16_p256"); return 0; }
-        // 256 x 256 LDS-DMA ring kernel: opt-in (mvuld_set_gemm_256_min_k / MVULD_GEMM_256 = minimum K, 0 = off, the default:
-        // in the full step it is a wash -- faster alone from K >= 1536, slower cold and on partial last rounds at 1 workgroup / CU)
-        int k256 = g_k256.load(std::memory_order_relaxed);
-        if (k256 < 0) {
-            const char* e = getenv("MVULD_GEMM_256");
-            k256 = e ? atoi(e) : 0;
-            g_k256.store(k256, std::memory_order_relaxed);
-        }
-        const int tiles_m2 = (int)cdiv(M, G2_BM), tiles_n2 = (int)cdiv(N, G2_BN);
-        if (k256 > 0 && splitk == 1 && out_mode == OUT_STORE && K % G2_BK == 0 && K >= k256 && (int64_t)tiles_m2 * tiles_n2 * batch >= 128) {
-            dim3 grid2(tiles_m2 * tiles_n2, batch);
-            static const bool attr2 = [] {               // function-local static: initialised once, thread-safe (C++11)
-                (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_256<float>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_nt_mfma_bf16_256<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-                return true;
-            }();
-            (void)attr2;
-            if (dtype_out == MVULD_F32) hipLaunchKernelGGL((gemm_nt_mfma_bf16_256<float>), grid2, dim3(512), G2_LDS_BYTES, stream, g, tiles_m2, tiles_n2);
-            else hipLaunchKernelGGL((gemm_nt_mfma_bf16_256<bf16>), grid2, dim3(512), G2_LDS_BYTES, stream, g, tiles_m2, tiles_n2);
-            MV_LAUNCH_CHECK("gemm_nt_mfma_bf16_256");
-            return 0;
-        }
         const int tiles_m = (int)cdiv(M, GT_BM), tiles_n = (int)cdiv(N, GT_BN);
         dim3 grid(tiles_m * tiles_n, batch * splitk);
         // 128 x 128 LDS-DMA ring for contractions up to MVULD_GEMM_RING_MAXK (default 2304; 0 = never): +8..15 % on the short-K

@@ -561,12 +561,6 @@ static int p256_num_cus() {
     return n;
 }
 
-// MVULD_P256_STAGES = 4 (default) | 5 (tiles below 256 rows only).  Measured: five stages make the isolated products 1.2 % faster
-// (19.55 vs 19.78 ms per step's worth) and the whole multi-stream step 0.3 % slower (60.5 vs 60.3 ms, two runs each): kept as a switch.
-static int p256_stages() {
-    static const int n = [] { const char* e = getenv("MVULD_P256_STAGES"); const int v = e ? atoi(e) : 4; return v == 5 ? 5 : 4; }();
-    return n;
-}
 // Ping-pong schedule of the two wave rows (template parameter PP): 1 = on (default), 0 = the lockstep loop.  Initialised from
 // MVULD_P256_PINGPONG; mvuld_set_gemm_p256_pingpong() overrides it (tests, A/B timing).  Results are bit-identical either way.
 #include <atomic>
@@ -602,23 +596,8 @@ extern "C" int mvuld_set_gemm_p256_k64(int on) {
     return 0;
 }
 
-// early issue of the next tile's step ahead of the epilogue's stores (template parameter EI; bf16 full-line ring): MVULD_P256_EARLY,
-// mvuld_set_gemm_p256_early (tests, A/B timing).  Bit-identical results.
-static std::atomic<int> g_p256_early{-1};
-static bool p256_early() {
-    int v = g_p256_early.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("MVULD_P256_EARLY");
-        v = e ? (atoi(e) != 0) : P256_EARLY_DEFAULT;
-        g_p256_early.store(v, std::memory_order_relaxed);
-    }
-    return v != 0;
-}
-extern "C" int mvuld_set_gemm_p256_early(int on) {
-    g_p256_early.store(on ? 1 : 0, std::memory_order_relaxed);
-    return 0;
-}
-
+// (Round 4: the early-issue variant -- template parameter EI -- and the five-stage ring -- NS = 5 -- measured neutral / negative in rounds 2-3
+// and are no longer instantiated: tools/experiments/README.md.  The kernel keeps the template parameters.)
 template <int EPI, int NI>
 static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int tiles_m = (int)cdiv(g.M, 32 * NI);
@@ -626,16 +605,6 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
     if (p256_k64() && g.K % 64 == 0 && (int64_t)g.M * g.lda * 2 < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb * 2 < ((int64_t)1 << 32)) {
         constexpr int NS6 = NI <= 5 ? 3 : 2;
-        if (p256_early()) {
-            constexpr int LDSE = NS6 * (NI * 4096 + 32768) + 3072;
-            static const bool attre = [] {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSE);
-                return true;
-            }();
-            (void)attre;
-            hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, true>), dim3(grid), dim3(512), LDSE, stream, g, tiles_m, tiles_n);
-            return;
-        }
         if constexpr (NI <= 5) {
             // MVULD_P256_K64_NS2=1: two stages below 192 rows too (A/B of the ring depth on one tile shape)
             static const bool two = [] { const char* e = getenv("MVULD_P256_K64_NS2"); return e && atoi(e) != 0; }();
@@ -674,7 +643,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n);
         return;
     }
-    if (p256_pingpong() && (NI > 7 || p256_stages() != 5)) {
+    if (p256_pingpong()) {
         static const bool attrp = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
             return true;
@@ -682,18 +651,6 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
         (void)attrp;
         hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
         return;
-    }
-    if constexpr (NI <= 7) {
-        if (p256_stages() == 5) {
-            constexpr int LDS5 = 5 * (2 * NI * 1024 + 16384) + 2048;
-            static const bool attr5 = [] {
-                (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS5);
-                return true;
-            }();
-            (void)attr5;
-            hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 5>), dim3(grid), dim3(512), LDS5, stream, g, tiles_m, tiles_n);
-            return;
-        }
     }
     static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);

@@ -454,7 +454,7 @@ def dgelu_epi(aux):
     return hip.EPI_MUL_AUX if (aux is not None and USE_GELU_DG[0]) else hip.EPI_MUL_DGELU
 
 
-# fused MLP (csrc/mlp_panel.hip): widest block width that takes it -- 0 = never, 128 (default) = Swin stage 0, 256 = stages 0 and 1
+# fused MLP (csrc/mlp_panel.hip): widest block width that takes it -- 0 = never, 128 (default) = Swin stage 0 (the library builds C = 128 only)
 FUSED_MLP_MAX_C = [int(os.environ.get("MVULD_FUSED_MLP", "128"))]
 FUSED_MLP_TRAIN = [os.environ.get("MVULD_FUSED_MLP_TRAIN", "1") != "0"]      # also in training (forward + recomputing backward)
 
