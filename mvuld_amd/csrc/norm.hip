@@ -502,6 +502,10 @@ extern "C" int mvuld_layernorm_bwd(const void* dy, const void* x, const float* g
         MV_LAUNCH_CHECK("layernorm_bwd_vec");
         return 0;
     }
+    // The partials-only form (dgamma == dbeta == NULL: the caller reduces `ws` itself, mvuld_layernorm_bwd_reduce_batch) exists on the vector
+    // path above only: a caller that sized its deferral with mvuld_layernorm_bwd_nparts but handed misaligned operands would otherwise have
+    // an uninitialised workspace reduced into its parameter gradients
+    MV_CHECK_ARG(dgamma || dbeta, "layernorm_bwd: the partials-only form (dgamma = dbeta = NULL) needs bf16 operands, C %% 8 == 0 and 16-byte aligned dy / x / dx / gamma");
     const int grid = (int)min((int64_t)1024, cdiv(rows, 4));
     if (dtype == MVULD_F32)
         hipLaunchKernelGGL(layernorm_bwd_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)dy, (const float*)x,

@@ -85,7 +85,7 @@ class FusedMVulD(nn.Module):
             g.ndata["_UNIX_NODE_EMB"] = self.unixcoder.encode_lines(node_ids, node_lens).float()
             self.unixcoder.train(was)
         if torch.is_grad_enabled() and self.training:
-            ops.ZERO_POOL.begin_step()
+            ops.begin_step()
         if not concurrent:
             ops.WGRAD_STREAM[0] = None
             ops.on_backward_done("unixcoder", None, key="fused-join")

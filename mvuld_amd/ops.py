@@ -21,6 +21,9 @@ USE_SPLIT3 = [False]                 # fp32 GEMMs (the head's fp32 tail) as 3-te
 SPLIT3_IN_REGISTERS = [os.environ.get("MVULD_SPLIT3_FUSED", "1") != "0"]      # ... split inside the GEMM kernel (0: two split launches + a 3K-deep product)
 SPLIT3_TRANS = [os.environ.get("MVULD_SPLIT3_TRANS", "1") != "0"]             # ... Rs_GCN's R^T dY / dR ph products read their operands as stored (no transposes)
 SPLIT3_WGRAD = [os.environ.get("MVULD_SPLIT3_WGRAD", "1") != "0"]             # ... the head's weight gradients as one such launch (0: two casts + the bf16 kernel)
+# NOTE: with SPLIT3_WGRAD the token contraction of a head weight gradient is split over workgroups that add into .grad with
+# fp32 atomics -- the order of those additions is not fixed, so the head's gradients (and a training run) are reproducible to fp32 rounding of
+# the sum order, not bit for bit, for a fixed seed.  MVULD_SPLIT3_WGRAD=0 restores the ordered slab reduction (exact-equality tests use it).
 USE_TN_WGRAD = [True]                # bf16 weight gradients through the transpose-free TN kernel
 USE_TN_SLABS = [os.environ.get("MVULD_TN_SLABS", "1") != "0"]     # ... whose split contraction (2..8 ways) goes through a slab workspace, not atomics
 
@@ -53,6 +56,16 @@ def fire_backward_done(tag):
         fn()
     if tag == "swin":
         WGRAD_STREAM[0] = None            # the step's backward is over: later launches (other models, tests) stay on their own stream
+
+
+def begin_step():
+    """Called where a training step starts (FusedMVulD.forward): drops whatever a backward that raised left deferred -- LayerNorm
+    parameter-gradient partials, an open weight-gradient group -- so that it cannot reach this step's gradients, and
+    arms the zeroed-scratch pool."""
+    del _LN_PENDING[:]
+    if _WGRAD_PENDING[0]:
+        del _WGRAD_PENDING[0][:]
+    ZERO_POOL.begin_step()
 
 
 class _ZeroPool:
