@@ -272,7 +272,6 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
         pp(1)
         k64(K64_DEFAULT)
-        early(EARLY_DEFAULT)
 
 
 @pytest.mark.parametrize("dtype,C", [(torch.bfloat16, 768), (torch.bfloat16, 520), (torch.bfloat16, 100), (torch.float32, 768)])
