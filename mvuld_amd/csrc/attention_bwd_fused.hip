@@ -33,9 +33,11 @@ typedef float __attribute__((ext_vector_type(16))) f32x16_t;
 #if AF_X == 9
 __device__ long long af_stamps[4][32];          // in-kernel stamps (shader cycles) of workgroup 0, step 5: cdna_hip_programming.md section 7
 #define AF_STAMP(i) do { if (blockIdx.x == 0 && qy == 5 && lane == 0) af_stamps[wave][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AF_KSTAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) af_stamps[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int mvuld_debug_af_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(af_stamps), sizeof(af_stamps)) == hipSuccess ? 0 : 1; }
 #else
 #define AF_STAMP(i) do { } while (0)
+#define AF_KSTAMP(i) do { } while (0)
 #endif
 #define AF_RPW 7            // key rows per wave
 #define AF_WAVES 4
@@ -207,40 +209,44 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
     // them; 60 consecutive words per wave and step): zeroed here, ordered before the first atomic by the barrier behind the staging
     for (int i = tid; i < T2; i += blockDim.x) pout[i] = 0.f;
 
+    AF_KSTAMP(16);
     const float tau = __expf(fminf(logit_scale[h], LN100));
     const int nwx = g.res / ws, wy = w / nwx, wx = w % nwx;
-    // ---- stage K^ (normalised) and V; chunk c of position n: threads 4n .. 4n+3
-    for (int c0 = tid; c0 < KR * 4; c0 += 4 * blockDim.x) {
-        U8 xk[4], xv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * blockDim.x, n = c >> 2;
-            xk[u].u = make_uint4(0, 0, 0, 0); xv[u].u = xk[u].u;
-            if (n < N) {
-                const bf16* p = qkv + am_token(g, b, w, n) * rs + C + h * HD + (c & 3) * 8;
-                xk[u].u = *(const uint4*)p;
-                xv[u].u = *(const uint4*)(p + C);
-            }
+    // ---- stage K^ (normalised) and V.  Everything global of the prologue goes out in ONE burst: K and V rows by LDS-DMA straight into their
+    // swizzled images (a DMA instruction fills 16 rows x 64 bytes in lane order, so the swizzle is applied to the SOURCE chunk a lane fetches:
+    // LDS slot sl of row n takes source chunk sl ^ ((x >> 2) & 3) -- an involution), the head's bias table as strided loads into registers, the
+    // first query row (below).  One wait, then the keys are normalised in place.  (First form: four register-staged batches of K / V, then the
+    // table, then the first row -- six global round trips in a row: 15 us of the 160 us a (window, head) takes at stage 2.)
+    {
+        const unsigned ki_a = __builtin_amdgcn_readfirstlane(af_lds_addr(Ki)), vi_a = __builtin_amdgcn_readfirstlane(af_lds_addr(Vi));
+        const int slot = lane & 3;
+        for (int j = wave; j < N / 16; j += AF_WAVES) {              // N = ws^2 with ws % 4 == 0: whole 16-row pieces
+            const int n = 16 * j + (lane >> 2), y = n / ws, x = n - y * ws;
+            const bf16* p = qkv + af_token(g, ws, b, wy, wx, y, x) * rs + C + h * HD + ((slot ^ ((x >> 2) & 3)) << 3);
+            af_dma16(p, ki_a + j * 1024);
+            af_dma16(p + C, vi_a + j * 1024);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * blockDim.x, n = c >> 2;
-            float f[8], ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] = (float)xk[u].e[e]; ss += f[e] * f[e]; }
-            ss += __shfl_xor(ss, 1, 64);
-            ss += __shfl_xor(ss, 2, 64);
-            const float sc = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xk[u].e[e] = (bf16)(f[e] * sc);
-            if (n < KR) {
-                const int o = af_off(n, n < N ? n % ws : 0, c & 3);
-                *(uint4*)(Ki + o) = xk[u].u;
-                *(uint4*)(Vi + o) = xv[u].u;
-            }
+        for (int i = N * 4 + tid; i < KR * 4; i += blockDim.x) {     // the rows behind the window (read 32 slots wide by the last key row): zeros
+            *(uint4*)(Ki + i * 8) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(Vi + i * 8) = make_uint4(0, 0, 0, 0);
         }
     }
-    for (int i = tid; i < T2 + 64; i += blockDim.x) tab[i] = i < T2 ? table16[(int64_t)i * g.H + h] * LOG2E : 0.f;
+    {
+        constexpr int TU = 13;                                       // table words per thread at ws = 28: (55^2 + 64) / 256
+        float tv[TU];
+        const int nt = (T2 + 64 + (int)blockDim.x - 1) / (int)blockDim.x;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int i = tid + u * (int)blockDim.x;
+            tv[u] = (u < nt && i < T2) ? table16[(int64_t)i * g.H + h] : 0.f;
+        }
+        for (int i = tid + TU * (int)blockDim.x; i < T2; i += blockDim.x) tab[i] = table16[(int64_t)i * g.H + h] * LOG2E;      // (larger tables: none here)
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int i = tid + u * (int)blockDim.x;
+            if (i < T2 + 64) tab[i] = tv[u] * LOG2E;
+        }
+    }
     for (int i = tid; i < AF_NEG; i += blockDim.x) negrow[i] = NEG_BIG;
 
     // ---- q-side tile of one query row.  Wave w fetches (LDS-DMA) and prepares rows 8 w .. 8 w + 7: lane (row = lane >> 3, pc = lane & 7), pc 0-3
@@ -292,10 +298,25 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
             if (pc == 4) Nd[buf * 32 + px] = pv ? -acc : 0.f;
         }
     };
+    AF_KSTAMP(17);
     q_issue(0);
     af_dma_wait();
+    __syncthreads();                                             // every wave's K / V pieces have landed
+    for (int c = tid; c < N * 4; c += blockDim.x) {              // k^ = k / |k| in place: the four slots of a row sit in four neighbouring lanes
+        U8 xk;
+        xk.u = *(const uint4*)(Ki + c * 8);
+        float f[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f[e] = (float)xk.e[e]; ss += f[e] * f[e]; }
+        ss = af_sum4(ss);
+        const float sc = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xk.e[e] = (bf16)(f[e] * sc);
+        *(uint4*)(Ki + c * 8) = xk.u;
+    }
     q_commit(0);
     __syncthreads();
+    AF_KSTAMP(18);
 
     // ---- per-lane fragment offsets inside a 32-row image (bf16 elements)
     const int qq = (lane & 15) >> 2, pp = lane & 3, grp = (lane >> 4) & 1;
@@ -537,6 +558,10 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
                 if (a == nrow - 1 && AF_X != 4) { gpend = gather(R[a]); dypend = qy - ky; }          // the chain ends at the wave's last key row
                 AF_STAMP(3 + a);
             }
+            // the next query row's tile (fetched by LDS-DMA since the top of the step) is normalised and published HERE, in the middle of the
+            // blocks: its LDS latencies and ~90 vector instructions then fall into the MFMA latencies of the block pipeline instead of
+            // standing alone in front of the barrier
+            if (a == 3 && qy + 1 < ws && AF_X != 3) { af_dma_wait(); q_commit(cur ^ 1); }
         }
         // ---- dQ of this query row: partial tile -> LDS (lane = query r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half)
         af_settle(dq);
@@ -544,7 +569,6 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         for (int gq = 0; gq < 4; ++gq)
             *(f32x4_t*)(Pw + r31 * AF_PQ + 8 * gq + 4 * hh) = (f32x4_t){dq[4 * gq], dq[4 * gq + 1], dq[4 * gq + 2], dq[4 * gq + 3]};
         AF_STAMP(10);
-        if (qy + 1 < ws && AF_X != 3) { af_dma_wait(); q_commit(cur ^ 1); }
         AF_STAMP(11);
         __syncthreads();
         AF_STAMP(12);
@@ -573,27 +597,36 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
         __syncthreads();
         AF_STAMP(14);
     }
+    AF_KSTAMP(19);
     // ---- the chains still open after the last query row (dy of chain a: ws - 1 - ky)
     if (dypend > AF_NODY) flush(gpend, dypend);
 #pragma unroll
     for (int a = 0; a < AF_RPW; ++a)
         if (a < nrow - 1) flush(gather(R[a]), ws - 1 - (ky0 + a));
-    // ---- dK, dV of the wave's key rows: lane = key position r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half
+    // ---- dK, dV of the wave's key rows: lane = key position r31, registers = dims (r & 3) + 8 (r >> 2) + 4 half.
+    // The raw keys of ALL the wave's rows (normalisation backward) are requested first, in one burst: one global round trip per workgroup
+    // instead of one per key row (seven dependent ones were 10 us of the 150 us a (window, head) takes at stage 2)
+    U4 kraw[AF_RPW][4];
+    int64_t ktok[AF_RPW];
 #pragma unroll
     for (int a = 0; a < AF_RPW; ++a) {
-        af_settle(dk[a]);
-        af_settle(dv[a]);
+        ktok[a] = af_token(g, ws, b, wy, wx, min(ky0 + a, ws - 1), min(r31, ws - 1));
+        const bf16* kp = qkv + ktok[a] * rs + C + h * HD + 4 * hh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) kraw[a][gq].u = *(const uint2*)(kp + 8 * gq);
+    }
+#pragma unroll
+    for (int a = 0; a < AF_RPW; ++a) {
+        // (their last MFMA retired a whole dQ-slice epilogue and two barriers ago: an ordering fence for hipcc, no wait states)
+        asm volatile("" : "+a"(dk[a]));
+        asm volatile("" : "+a"(dv[a]));
         if (a < nrow) {
-            const int ky = ky0 + a;
-            const int64_t t = af_token(g, ws, b, wy, wx, ky, min(r31, ws - 1));
-            const bf16* kp = qkv + t * rs + C + h * HD + 4 * hh;
+            const int64_t t = ktok[a];
             float kh[16], ss = 0.f;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                U4 x;
-                x.u = *(const uint2*)(kp + 8 * gq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { kh[4 * gq + e] = (float)x.e[e]; ss += kh[4 * gq + e] * kh[4 * gq + e]; }
+                for (int e = 0; e < 4; ++e) { kh[4 * gq + e] = (float)kraw[a][gq].e[e]; ss += kh[4 * gq + e] * kh[4 * gq + e]; }
             }
             ss += __shfl_xor(ss, 32, 64);
             const float kinv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -617,6 +650,7 @@ __global__ __launch_bounds__(64 * AF_WAVES) void attn_bwd_fused_win_k(AttnGeom g
             }
         }
     }
+    AF_KSTAMP(20);
     dtau_part = wave_sum(dtau_part);
     if (lane == 0) red[wave] = dtau_part;
     __syncthreads();

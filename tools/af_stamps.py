@@ -27,3 +27,5 @@ names = ["top", "q_issue", "frags", "blk0", "blk1", "blk2", "blk3", "blk4", "blk
 for w in range(4):
     st = [buf[w * 32 + i] for i in range(15)]
     print(f"wave {w}: total {st[14] - st[0]} cycles | " + " ".join(f"{names[i]}+{st[i] - st[i - 1]}" for i in range(1, 15)))
+    k = [buf[w * 32 + i] for i in range(16, 21)]
+    print(f"        kernel phases: staging K/V/table {k[1] - k[0]}, first row fetch+commit {k[2] - k[1]}, {ws} steps {k[3] - k[2]} ({(k[3] - k[2]) // ws} per step), tail (chain flush, dK/dV epilogue) {k[4] - k[3]}, whole {k[4] - k[0]}")
