@@ -15,6 +15,7 @@ BASELINE.md section 4 protocol; N=1 only) and ``inference`` (BASELINE configs[3]
 hipGraph and replayed; N=1 only).  ``--mode infer --batch 256`` prints that leg as the headline line instead.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -69,7 +70,8 @@ def build(args, device, rank):
     from mvuld_amd.lr_scheduler import build_scheduler
     from mvuld_amd.data import synthetic
     a = types.SimpleNamespace(cfg=args.cfg, opts=(args.opts or []) + ["FUSED.DTYPE", args.dtype], batch_size=args.batch, local_rank=0)
-    config = get_config(a)
+    with contextlib.redirect_stdout(sys.stderr):       # the reference-style "=> merge config from ..." line: stdout carries the JSON line only
+        config = get_config(a)
     torch.manual_seed(12345)
     model = build_fused_model(config).to(device).train()
     opt = build_optimizer(config, model)

@@ -101,6 +101,14 @@ int mvuld_set_gemm_p256_mode(int mode);
 /* Tile height of that kernel: 0 = chosen per shape so the tiles fill whole rounds of the persistent grid (default),
  * or 128 / 160 / 192 / 224 / 256 rows for every launch (A/B timing, tests). */
 int mvuld_set_gemm_p256_rows(int rows);
+/* Tile walk of that kernel on launches with more tiles than workgroups: 0 = static (workgroup b owns tiles b, b + G, ...),
+ * 1 = dynamic: only a workgroup's first tile is fixed, the others are claimed from per-XCD counters, so a workgroup whose CU was held by
+ * another kernel when the launch began (a collective's channels, another stream's persistent grid) claims what is left instead of owning
+ * a full share; 2 = the first tile is claimed too (one exposed ~2 us round trip per launch; no tile waits for a workgroup that has not
+ * started: the mode for runs with a resident collective, mvuld_amd/distributed.py selects it).  Bit-identical results (same tiles, same
+ * arithmetic per tile); the library keeps one 64-byte counter block per stream.  Launches on a stream under capture keep the static
+ * walk.  MVULD_GEMM_DYNAMIC_TILES. */
+int mvuld_set_gemm_dynamic_tiles(int mode);
 /* Schedule of that kernel's main loop: 1 (default) = ping-pong -- the two waves of every SIMD run half a k-step apart, one reading its
  * fragments from LDS while the other owns the matrix pipe; 0 = both in lockstep (one barrier per k-step).  Bit-identical results;
  * initialised from MVULD_P256_PINGPONG (A/B timing, tests). */

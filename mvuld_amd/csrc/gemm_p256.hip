@@ -18,6 +18,7 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 
 #define P_BN 256
 #ifndef P256_X
@@ -33,9 +34,12 @@
 #ifndef P256_EARLY_DEFAULT
 #define P256_EARLY_DEFAULT 0
 #endif
+#ifndef P256_DYNAMIC_DEFAULT
+#define P256_DYNAMIC_DEFAULT 0
+#endif
 #define P_STAGE_BYTES 32768
 #define P_BIAS_OFF (4 * P_STAGE_BYTES)                 // two 1 KiB bias slices (256 fp32 columns), alternating per tile
-#define P_LDS_BYTES (4 * P_STAGE_BYTES + 2048)
+#define P_LDS_BYTES (4 * P_STAGE_BYTES + 2048 + 64)
 
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [256][32] bf16 tile (64-byte rows): slot XORed with the row group so
 // that every 16-lane group of a ds_read_b128 fragment read covers all 64 banks (same image as gemm.hip's ring kernels)
@@ -100,7 +104,7 @@ typedef long __attribute__((ext_vector_type(2))) i64x2_t;
 // then waits for (nearly) all of a tile's stores in front of the last rows' aux values (section 9b item 15 of DESIGN.md); without the
 // branch the waits are counted.
 template <int EPI, int NI, bool FP8 = false, int NS = 4, bool PP = false, bool K64 = false, bool EI = false, bool NF = false>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tiles_m, int tiles_n, unsigned* dynp = nullptr, int dyn_all = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_vp;
     typedef __attribute__((address_space(1))) const void* glb_vp;
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     static_assert(!K64 || (PP && (NS == 2 || (NS == 3 && NI <= 5))), "128-byte stages: ping-pong, 2 stages (3 at <= 160 rows)");
     static_assert(!EI || K64, "early issue belongs to the full-line ring");
     constexpr int NBS = EI ? 3 : 2;                     // bias slices
-    static_assert(NS * STAGE + NBS * 1024 <= 163840, "ring does not fit the LDS");
+    static_assert(NS * STAGE + NBS * 1024 + 64 <= 163840, "ring does not fit the LDS");
+    constexpr int CLAIM_OFF = BIAS_OFF + NBS * 1024;    // two claimed tile positions (dynamic tile walk), alternating per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // 2 x 4 waves, WM (m) x 64 (n) each
@@ -122,15 +127,39 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     const int G = gridDim.x, bx = blockIdx.x;
     constexpr int ES = FP8 ? 1 : 2;                      // bytes per operand element; a k-step is always 64 bytes of every row
     const int nk = g.K * ES / RB;
-    const int my_tiles = bx < nt ? (nt - bx + G - 1) / G : 0;
-    const int total = my_tiles * nk;
+    // DYNAMIC TILE WALK (dynp != nullptr; host: K64 ring, nt > G, G % 8 == 0, nk >= NS + 1).  The static walk gives workgroup b the tiles
+    // b, b + G, ...: a workgroup that starts late -- its CU was held by another kernel: a collective's channels, another stream's
+    // persistent grid -- still owns its whole share and the launch lasts two shares.  Here only the first tile is fixed (position b: no
+    // round trip in front of the first loads); every further one is claimed from a counter of the workgroup's XCD (positions of residue
+    // b & 7 are that XCD's contiguous run of tiles, so an A row panel is still pulled from HBM by one L2): a late workgroup claims what is
+    // left, usually nothing.  (dyn_all: the first tile is claimed too -- one exposed round trip per launch, ~2 us, and no tile is owned by
+    // a workgroup that has not started: what a launch beside a resident collective wants, section 7 of DESIGN.md.)  The claim is a SCALAR atomic (s_atomic_add ... glc: tools/microbench/scalar_atomic.hip shows gfx950 executes
+    // them, coherently across XCDs): its ticket returns into an SGPR under lgkmcnt, so it neither enters the vector-memory queue -- a
+    // returning vector atomic would sit in vmcnt behind a tile's stores and in front of the next loads -- nor needs a register the
+    // epilogue could spill.  Wave 0 issues the claim for tile k + 1 when tile k - 1's epilogue is done, publishes the position through LDS
+    // in front of the first hand-over barrier of tile k (its lgkmcnt(0) after the fragment reads has retired the ticket), and every wave
+    // reads it when its DMA stream leaves tile k, at k-step nk - NS >= 1.  One failing claim per workgroup ends its walk; the G-th workgroup
+    // to finish zeroes the counters for the next launch on the stream.  Same tiles, same arithmetic per tile: bit-identical output.
+    const bool dyn = K64 && dynp != nullptr;
+    int my_tiles = bx < nt ? (dyn ? 1 : (nt - bx + G - 1) / G) : 0;
+    int total = my_tiles * nk;
+    int p_iss = bx, p_cmp = bx;                          // tile positions of the DMA stream / of the compute stream
+    // The ticket is in flight across compiled code, so it must not be an asm OUTPUT: hipcc copies an output operand into the variable's
+    // register right behind the statement, i.e. before the value has landed (first build's ISA, with "=s" and with "+s" alike).  It lives in
+    // s101, which hipcc never allocates on this target (it reports s100 / s101 as reserved; naming it as a clobber makes the kernel
+    // descriptor cover it) and which only these statements touch; it becomes a C++ value behind the lgkmcnt(0) that retires it.
+    bool claim_fly = false;
+    auto claim_issue = [&]() {                           // wave 0 only
+        asm volatile("s_mov_b32 s101, 1\n\ts_atomic_add s101, %0, 0x0 glc" ::"s"(dynp + (bx & 7)) : "memory", "s101");
+        claim_fly = true;
+    };
+    const unsigned claim_a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + CLAIM_OFF);
     const char* A = (const char*)g.A;
     const char* B = (const char*)g.B;
     bf16* C = (bf16*)g.C;
     bf16* aux = (bf16*)g.aux;
 
-    auto tile_of = [&](int ord, int& m0, int& n0) {      // ord-th tile of this workgroup
-        const int p = bx + ord * G;
+    auto tile_of = [&](int p, int& m0, int& n0) {        // tile at position p of the XCD-contiguous order
         const int q = nt >> 3, r = nt & 7, x = p & 7, i = p >> 3;
         const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
         m0 = (t / tiles_n) * BM;
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
     int iss_ord = 0, iss_kt = 0, issued = 0;
     auto setup_ptrs = [&](int ord) {
         int m0, n0;
-        tile_of(ord, m0, n0);
+        tile_of(p_iss, m0, n0);
         if constexpr (K64) {
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
@@ -203,10 +232,42 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             ++issued;
             if (++iss_kt == nk) {
                 iss_kt = 0;
-                if (++iss_ord < my_tiles) setup_ptrs(iss_ord);
+                ++iss_ord;
+                if (dyn) {
+                    int p;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(p) : "v"(claim_a + (iss_ord & 1) * 4) : "memory");
+                    p = __builtin_amdgcn_readfirstlane(p);
+                    if (p >= 0) {
+                        p_iss = p;
+                        ++my_tiles;
+                        total += nk;
+                        setup_ptrs(iss_ord);
+                    }
+                } else if (iss_ord < my_tiles) {
+                    p_iss = bx + iss_ord * G;
+                    setup_ptrs(iss_ord);
+                }
             }
         }
     };
+    const int dyn_base = dyn_all ? 0 : G;                // position of ticket t: (b & 7) + dyn_base + 8 t
+    if (dyn && dyn_all) {
+        if (wave == 0) {
+            claim_issue();
+            unsigned ticket;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, s101" : "=s"(ticket)::"s101", "memory");
+            const int pn = (bx & 7) + 8 * (int)ticket;
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(claim_a), "v"(pn < nt ? pn : -1) : "memory");
+            claim_fly = false;
+        }
+        __builtin_amdgcn_s_barrier();
+        int p;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(p) : "v"(claim_a) : "memory");
+        p = __builtin_amdgcn_readfirstlane(p);
+        p_iss = p_cmp = p < 0 ? 0 : p;
+        if (p < 0) my_tiles = total = 0;
+    }
+    if (dyn && wave == 0 && my_tiles > 0) claim_issue();     // the second tile's claim: in flight under the first tile's prologue
     if (my_tiles > 0) setup_ptrs(0);
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i) issue_one();
@@ -307,6 +368,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
 #pragma unroll
                     for (int i = 0; i < NI; ++i) fa[i] = *(const frag_t*)(st + (oa[i] ^ (h * 64)));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (dyn && h == 0 && kt == 0 && wave == 0 && claim_fly) {      // the ticket has landed (lgkmcnt(0) above): publish tile ord + 1
+                        unsigned ticket;
+                        asm volatile("s_mov_b32 %0, s101" : "=s"(ticket)::"s101");
+                        const int pn = (bx & 7) + dyn_base + 8 * (int)ticket;
+                        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(claim_a + ((ord + 1) & 1) * 4), "v"(pn < nt ? pn : -1) : "memory");
+                        claim_fly = false;
+                    }
                     if (h == 1 && wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1, prev);
                     __builtin_amdgcn_s_barrier();
                     // EI: the tile's last stage has now been read by every wave: the next tile's step NS - 1 goes out ahead of the stores
@@ -398,11 +466,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
 
         // ---- epilogue, straight from the accumulators:  acc[i][j][r] = C[m0 + wr*WM + i*16 + fr][n0 + wc*64 + j*16 + 4*fg + r]
         int m0, n0;
-        tile_of(ord, m0, n0);
+        tile_of(dyn ? p_cmp : bx + ord * G, m0, n0);
+        p_cmp = p_iss;                                   // dynamic walk: the DMA stream is in the next tile by now, and not beyond it (nk > NS)
         const int nw = n0 + wc * 64, mw = m0 + wr * WM;
         if constexpr (NF) {
-            if (nw >= g.N) { pend = 0; continue; }       // wave-uniform: nothing of this wave's 64 columns exists
+            if (nw >= g.N) { pend = 0; continue; }       // wave-uniform: nothing of this wave's 64 columns exists (never wave 0: wc = 0)
         }
+        // tile ord + 2's claim, published during tile ord + 1: issued here so that the whole epilogue covers its round trip (behind the last
+        // store the ticket was still in flight at wave 0's first lgkmcnt(0) of the next tile: +3..5 % on the K = 512 products)
+        if (dyn && wave == 0 && ord + 1 < my_tiles) claim_issue();
         float alpha = g.alpha;
         if (FP8) alpha *= (g.scale_a ? g.scale_a[0] : 1.0f) * (g.scale_b ? g.scale_b[0] : 1.0f);      // per-tensor dequantisation
         const float qinv = QE ? 1.0f / g.q_scale[0] : 0.f;
@@ -543,6 +615,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
         const bool interior = NF || ((mw + WM <= g.M) && (nw + 64 <= g.N));      // wave-uniform: every store above was issued
         pend = interior ? ST1 * ((C ? 1 : 0) + ((IS_GELU && aux) ? 1 : 0) + (QE ? 1 : 0)) : 0;
     }
+    if (dyn && wave == 0) {
+        unsigned done;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(done) : "s"(dynp + 8), "0"(1u) : "memory");
+        if (done == (unsigned)G - 1 && lane < 9) __hip_atomic_store(dynp + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (FP8 && (EPI == EPI_GELU || EPI == EPI_GELU_DG)) {
         if (QE) {
             const float m = wave_max(amax_l);
@@ -596,6 +673,61 @@ extern "C" int mvuld_set_gemm_p256_k64(int on) {
     return 0;
 }
 
+// ---- dynamic tile walk: knob and per-stream counter blocks
+// MVULD_GEMM_DYNAMIC_TILES / mvuld_set_gemm_dynamic_tiles: 0 = static walk, 1 = dynamic walk wherever a launch has more tiles than workgroups,
+// 2 = the same with the first tile claimed too.
+// A block is 16 words (8 per-XCD counters, the finished-workgroup count), all zero between launches (the kernel's last workgroup restores
+// them), one block per stream: launches of a stream are ordered, launches of different streams must not share tickets.  The pool is
+// allocated once, outside any capture; a stream that is being captured gets the static walk (a replay could run beside the stream whose
+// block the captured pointer names), and so does the 65th stream.
+static std::atomic<int> g_p256_dyn{-1};
+static bool p256_dynamic() {
+    int v = g_p256_dyn.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MVULD_GEMM_DYNAMIC_TILES");
+        v = e ? atoi(e) : P256_DYNAMIC_DEFAULT;
+        if (v < 0 || v > 2) v = P256_DYNAMIC_DEFAULT;
+        g_p256_dyn.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int mvuld_set_gemm_dynamic_tiles(int mode) {
+    MV_CHECK_ARG(mode >= 0 && mode <= 2, "set_gemm_dynamic_tiles: mode must be 0, 1 or 2");
+    g_p256_dyn.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+unsigned* mvuld_dyn_counter_block(hipStream_t stream) {
+    constexpr int NBLK = 64;
+    static std::mutex mu;
+    static unsigned* pool = nullptr;
+    static bool failed = false;
+    static hipStream_t owner[NBLK];
+    static int used = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (failed) return nullptr;
+    if (!pool) {
+        if (hipMalloc((void**)&pool, NBLK * 64) != hipSuccess || hipMemset(pool, 0, NBLK * 64) != hipSuccess) {
+            (void)hipGetLastError();
+            pool = nullptr;
+            failed = true;
+            return nullptr;
+        }
+    }
+    for (int i = 0; i < used; ++i)
+        if (owner[i] == stream) return pool + i * 16;
+    if (used == NBLK) return nullptr;
+    owner[used] = stream;
+    return pool + 16 * used++;
+}
+// the walk a launch of `nt` tiles of `nk` ring steps on `grid` workgroups takes: the counter block, or null = static
+static unsigned* p256_dyn_for(hipStream_t stream, int nt, int grid, int nk, int ns) {
+    if (!p256_dynamic() || nt <= grid || (grid & 7) != 0 || nk < ns + 1) return nullptr;
+    return mvuld_dyn_counter_block(stream);
+}
+static int p256_dyn_all() { return g_p256_dyn.load(std::memory_order_relaxed) == 2; }
+
 // (Round 4: the early-issue variant -- template parameter EI -- and the five-stage ring -- NS = 5 -- measured neutral / negative in rounds 2-3
 // and are no longer instantiated: tools/experiments/README.md.  The kernel keeps the template parameters.)
 template <int EPI, int NI>
@@ -609,17 +741,19 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
             // MVULD_P256_K64_NS2=1: two stages below 192 rows too (A/B of the ring depth on one tile shape)
             static const bool two = [] { const char* e = getenv("MVULD_P256_K64_NS2"); return e && atoi(e) != 0; }();
             if (two) {
-                constexpr int LDS2 = 2 * (NI * 4096 + 32768) + 2048;
+                constexpr int LDS2 = 2 * (NI * 4096 + 32768) + 2048 + 64;
                 static const bool attr2 = [] {
                     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
                     return true;
                 }();
                 (void)attr2;
-                hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>), dim3(grid), dim3(512), LDS2, stream, g, tiles_m, tiles_n);
+                hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>), dim3(grid), dim3(512), LDS2, stream, g, tiles_m, tiles_n,
+                                   p256_dyn_for(stream, nt, grid, g.K / 64, 2), p256_dyn_all());
                 return;
             }
         }
-        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
+        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048 + 64;
+        unsigned* dynp = p256_dyn_for(stream, nt, grid, g.K / 64, NS6);
         if constexpr (epi_reads_aux(EPI)) {
             // unconditional-store epilogue (template parameter NF) wherever every wave's 64 columns are all inside or all outside the
             // matrix and the output does not alias the aux operand: bit-identical, -2..8 % on these products
@@ -631,7 +765,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
                 }();
                 (void)attrn;
                 hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true, false, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m,
-                                   tiles_n);
+                                   tiles_n, dynp, p256_dyn_all());
                 return;
             }
         }
@@ -640,7 +774,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
             return true;
         }();
         (void)attr6;
-        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n, dynp, p256_dyn_all());
         return;
     }
     if (p256_pingpong()) {
@@ -649,7 +783,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
             return true;
         }();
         (void)attrp;
-        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, false, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
         return;
     }
     static const bool attr = [] {
@@ -657,7 +791,7 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
         return true;
     }();
     (void)attr;
-    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
 }
 
 template <int EPI>
@@ -702,13 +836,13 @@ static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t strea
     const int grid = nt < p256_num_cus() ? nt : p256_num_cus();
     if (p256_k64() && g.K % 128 == 0 && (int64_t)g.M * g.lda < ((int64_t)1 << 32) && (int64_t)g.N * g.ldb < ((int64_t)1 << 32)) {
         constexpr int NS6 = NI <= 5 ? 3 : 2;
-        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048;
+        constexpr int LDS6 = NS6 * (NI * 4096 + 32768) + 2048 + 64;
         static const bool attr6 = [] {
             (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, true, NS6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS6);
             return true;
         }();
         (void)attr6;
-        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, NS6, true, true>), dim3(grid), dim3(512), LDS6, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
         return;
     }
     if (p256_pingpong()) {
@@ -717,10 +851,10 @@ static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t strea
             return true;
         }();
         (void)attrp;
-        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true, 4, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
         return;
     }
-    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
 }
 static int p256_pick_ni(int M, int tiles_n, int cus);
 template <int EPI>

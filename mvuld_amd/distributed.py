@@ -70,6 +70,12 @@ def attach_gradient_exchange(store, max_bucket_elems=64 * 1024 * 1024, payload=N
     from . import ops
     reducer = GradAllReducer(store.grad, max_bucket_elems, payload=payload)
     store.grad_scale = 1.0 / world_size()
+    if reducer._active() and store.grad.is_cuda and "MVULD_GEMM_DYNAMIC_TILES" not in os.environ:
+        # the collectives' channels stay resident on some CUs for milliseconds while backward goes on beside them: the persistent NT grid then
+        # claims ALL its tiles at run time (include/mvuld_hip.h: mvuld_set_gemm_dynamic_tiles; with 8-64 CUs held, tools/microbench/
+        # cu_hog_gemm.hip measures the K = 512 products 13-24 % shorter than under the static walk, profiles/r04_dynamic_tiles.txt)
+        from . import hip
+        hip.LIB.fn("mvuld_set_gemm_dynamic_tiles")(2)
     tags = [f"swin.layers.{i}" for i in range(4)] + ["unixcoder"]
     for tag in tags:
         if reducer._active():

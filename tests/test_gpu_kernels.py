@@ -184,6 +184,7 @@ def _gemm_large_ragged(gpu, K):
     assert rel(aux, r.grad) < 1e-2 and rel(out, F.gelu(ref + bias)) < 1e-2
 
 
+DYN_DEFAULT = int(os.environ.get("MVULD_GEMM_DYNAMIC_TILES", "0"))      # keep in step with P256_DYNAMIC_DEFAULT of csrc/gemm_p256.hip
 K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "1"))      # keep in step with P256_K64_DEFAULT of csrc/gemm_p256.hip
 
 
@@ -210,6 +211,7 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     hip.LIB.fn("mvuld_set_gemm_p256_rows")(rows)       # tile height: 0 = chosen per shape, else forced
     pp = hip.LIB.fn("mvuld_set_gemm_p256_pingpong")
     k64 = hip.LIB.fn("mvuld_set_gemm_p256_k64")
+    dyn = hip.LIB.fn("mvuld_set_gemm_dynamic_tiles")
     k64(0)
 
     def both(**kw):
@@ -233,6 +235,16 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
                 assert torch.equal(o2, o1)
                 if a1 is not None:
                     assert torch.equal(a1, kw["aux"])
+            # the dynamic tile walk (tiles after a workgroup's first one claimed from per-XCD counters): same tiles, same arithmetic per
+            # tile (mode 2: the first tile claimed too); a launch would start from non-zero counters if the last workgroup of the one before it had not restored them
+            for mode in (1, 2, 1):
+                dyn(mode)
+                for _ in range(2):
+                    o3 = ops.gemm_nt(A, B_, **kw)
+                    assert torch.equal(o3, o1)
+                    if a1 is not None:
+                        assert torch.equal(a1, kw["aux"])
+            dyn(0)
             k64(0)
         return o1
     try:
@@ -272,6 +284,49 @@ def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
         hip.LIB.fn("mvuld_set_gemm_p256_rows")(0)
         pp(1)
         k64(K64_DEFAULT)
+        dyn(DYN_DEFAULT)
+
+
+def test_gemm_p256_dynamic_walk_beside_another_grid(gpu):
+    """The dynamic tile walk where it matters: two persistent grids on two streams at once, so that the workgroups of the launch that
+    comes second start late (their CUs are held: 160 KB of LDS per workgroup) and find the counters partly or wholly drained by the
+    workgroups that did start.  Every product must equal the one the static walk gave alone on the chip, launch after launch (a ticket
+    handed out twice or not at all is a tile written twice / never: the outputs are poisoned in between), and each stream has its own
+    counter block (shared tickets would skip tiles)."""
+    from mvuld_amd import ops, hip
+    dyn = hip.LIB.fn("mvuld_set_gemm_dynamic_tiles")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(25088, 1536, 512), (25088, 2048, 512), (25088, 512, 2048), (16384, 2304, 768), (100352, 384, 192), (6272, 4096, 1024)]
+    ops_ = []
+    for M, N, K in shapes:
+        a = (torch.rand((M, K), generator=g) - 0.5).to(torch.bfloat16).to(gpu)
+        b = (torch.rand((N, K), generator=g) - 0.5).to(torch.bfloat16).to(gpu)
+        bias = (torch.rand((N,), generator=g) - 0.5).to(gpu)
+        ops_.append((a, b, bias))
+    dyn(0)
+    want = [ops.gemm_nt(a, b, bias=bias) for a, b, bias in ops_]
+    wantg = [ops.gemm_nt(a, b, bias=bias, epi=hip.EPI_GELU, aux=torch.empty((a.shape[0], b.shape[0]), dtype=torch.bfloat16, device=gpu)) for a, b, bias in ops_]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        for rep in range(4):
+            dyn(1 + rep % 2)
+            got1, got2 = [], []
+            with torch.cuda.stream(s1):
+                for a, b, bias in ops_:
+                    got1.append(ops.gemm_nt(a, b, bias=bias))
+            with torch.cuda.stream(s2):
+                for a, b, bias in reversed(ops_):
+                    got2.append(ops.gemm_nt(a, b, bias=bias, epi=hip.EPI_GELU, aux=torch.empty((a.shape[0], b.shape[0]), dtype=torch.bfloat16, device=gpu)))
+            torch.cuda.synchronize()
+            for w, o in zip(want, got1):
+                assert torch.equal(w, o)
+                o.fill_(float("nan"))
+            for w, o in zip(reversed(wantg), got2):
+                assert torch.equal(w, o)
+                o.fill_(float("nan"))
+    finally:
+        dyn(DYN_DEFAULT)
 
 
 @pytest.mark.parametrize("dtype,C", [(torch.bfloat16, 768), (torch.bfloat16, 520), (torch.bfloat16, 100), (torch.float32, 768)])
