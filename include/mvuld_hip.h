@@ -67,7 +67,7 @@ int mvuld_gemm_nt_f32x3(const float* A, int64_t lda, int64_t strideA, const floa
  * swin_transformer_v2.py:146-152,177,26-32 and the RobertaModel dense layers behind unixcoder.py:36).
  * mvuld_quant_e4m3: per-tensor quantisation to OCP e4m3 (gfx950's native fp8): scale_out[0] = max|x| / 448, out = e4m3(x / scale);
  *   n % 8 == 0; `partials` = 1024 floats of scratch.
- * mvuld_gemm_nt_fp8: C[M,N] (bf16) = epi(scale_a[0] * scale_b[0] * A8[M,K] . B8[N,K]^T + bias) on v_mfma_f32_16x16x32_fp8_fp8 with fp32
+ * mvuld_gemm_nt_fp8: C[M,N] (bf16) = epi(scale_a[0] * scale_b[0] * A8[M,K] . B8[N,K]^T + bias) on the e4m3 matrix-core forms (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales where K >= 1024, v_mfma_f32_16x16x32_fp8_fp8 elsewhere) with fp32
  *   accumulation (the persistent 256 x 256 kernel; K % 64 == 0, K >= 256, N % 8 == 0, lda / ldb multiples of 16); epilogue NONE / BIAS /
  *   GELU (+ pre-activation to `aux`) / GELU_DG (+ gelu' to `aux`).  With a GELU epilogue the activation can leave as e4m3 for the next product without a pass of
  *   its own: q_out[M,N] (row stride ldq bytes) = e4m3(bf16(gelu) / q_state[0]); max|gelu| is folded into q_state[1] (atomic max on the

@@ -34,6 +34,10 @@
 #ifndef P256_EARLY_DEFAULT
 #define P256_EARLY_DEFAULT 0
 #endif
+#ifndef P256_FP8_SCALED
+#define P256_FP8_SCALED 1      // fp8 full-line ring on v_mfma_scale_f32_16x16x128_f8f6f4 (0: four v_mfma_f32_16x16x32_fp8_fp8 per stage and fragment pair)
+#endif
+#define P256_FP8_SCALED_MAX_NI 6
 #ifndef P256_DYNAMIC_DEFAULT
 #define P256_DYNAMIC_DEFAULT 0
 #endif
@@ -356,6 +360,58 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
             __builtin_amdgcn_s_barrier();                // step cs visible to every wave; every wave is done reading step cs - 1
             if (!(prev && kt == 0)) issue_one();         // step cs + NS - 1 refills the stage step cs - 1 occupied (EI: issued at the last tile's end)
             const char* st = smem + (cs % NS) * STAGE;
+            if constexpr (K64 && FP8 && (P256_FP8_SCALED != 0) && NI <= P256_FP8_SCALED_MAX_NI) {
+                // e4m3 on the block-scaled instruction: v_mfma_scale_f32_16x16x128_f8f6f4 takes 32 bytes of every operand row per lane and runs at
+                // twice the bf16 rate (the non-scaled 16x16x32_fp8_fp8 form runs AT the bf16 rate: four of them, 64 cycles, for what this one does
+                // in 32).  A 128-byte stage row is exactly one instruction's K: the lane takes the 16-byte chunk `fg` of BOTH 64-byte halves -- the
+                // two reads the sub-steps below make -- as one 8-register operand; weights and activations split K the same way, so it is a valid
+                // contraction (only the fp32 summation order differs from the non-scaled form).  Unit block scales (E8M0 127 in every byte); the
+                // per-tensor scales stay folded into alpha.  ONE read epoch and ONE matrix epoch per stage: two barriers instead of four, row 1 still
+                // one epoch behind row 0 (it reads stage c while row 0 multiplies it, and waits for its share of c + 1 before the barrier that
+                // opens row 0's read epoch of c + 1).
+                typedef int __attribute__((ext_vector_type(8))) i32x8_t;
+                typedef int __attribute__((ext_vector_type(4))) i32x4_t;
+                // Registers: 8 per fragment.  Up to 192 rows all NI + 4 fragments are read in the read epoch (80 registers beside 96 accumulators);
+                // at 224 / 256 rows that spills (first build: 47 / 69 VGPRs), and reading half of the activation fragments behind the first half's
+                // MFMAs is a RACE (the stage is handed back to the DMA by the barrier that ends the read epoch: row 0 refills it while row 1 is
+                // still in its matrix epoch -- caught by test_gemm_nt_fp8_vs_dequantised_product).  So: this path up to 192 rows, which is what the
+                // host picks for e4m3 products; taller tiles (forced by mvuld_set_gemm_p256_rows) keep the non-scaled sub-steps below.
+                constexpr int HA = NI;
+                i32x8_t fa[HA], fb[4];
+                auto rd = [&](int off) {
+                    const i32x4_t lo = *(const i32x4_t*)(st + off), hi = *(const i32x4_t*)(st + (off ^ 64));
+                    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = rd(ob[j]);
+#pragma unroll
+                for (int i = 0; i < HA; ++i) fa[i] = rd(oa[i]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wr == 1 && kt + 1 < nk) wait_step(kt + 1, cs + 1, prev);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < HA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if constexpr (HA < NI) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = HA; i < NI; ++i) fa[i - HA] = rd(oa[i]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = HA; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i - HA], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if constexpr (K64) {
                 // two 64-byte sub-steps (32 bf16 / 64 e4m3 deep), each a read epoch and a matrix epoch; row 1 runs one epoch behind row 0
                 typedef typename std::conditional<FP8, i64x2_t, bf16x8_t>::type frag_t;
@@ -739,8 +795,12 @@ static void p256_launch(const GemmArgs& g, int tiles_n, hipStream_t stream) {
         constexpr int NS6 = NI <= 5 ? 3 : 2;
         if constexpr (NI <= 5) {
             // MVULD_P256_K64_NS2=1: two stages below 192 rows too (A/B of the ring depth on one tile shape)
+            // A three-stage ring runs its DMA stream two steps ahead; on a two-step contraction (K = 128) that is a whole tile ahead, and the
+            // stream's NEXT wrap would refill the bias slice of the tile whose epilogue has not read it yet (two slices, alternating): the
+            // ring must not be deeper than the tile is long.  (Round 4: found through the e4m3 path, whose picks changed; the bf16 products of
+            // the step at K = 128 have N <= 512, where the tiles two apart share their bias columns, so it never showed.)
             static const bool two = [] { const char* e = getenv("MVULD_P256_K64_NS2"); return e && atoi(e) != 0; }();
-            if (two) {
+            if (two || g.K / 64 < 3) {
                 constexpr int LDS2 = 2 * (NI * 4096 + 32768) + 2048 + 64;
                 static const bool attr2 = [] {
                     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p256<EPI, NI, false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
@@ -856,10 +916,20 @@ static void p256_launch_fp8_ni(const GemmArgs& g, int tiles_n, hipStream_t strea
     }
     hipLaunchKernelGGL((gemm_nt_bf16_p256<EPI, NI, true>), dim3(grid), dim3(512), P_LDS_BYTES, stream, g, tiles_m, tiles_n, (unsigned*)nullptr, 0);
 }
-static int p256_pick_ni(int M, int tiles_n, int cus);
+static int p256_pick_ni(int M, int tiles_n, int cus, int max_ni = 8);
+static std::atomic<int> g_p256_ni{0};      // 0 = pick per shape; 4..8 = force (A/B timing)
+static int g_p256_ni_forced() { return g_p256_ni.load(std::memory_order_relaxed); }
 template <int EPI>
 static void p256_launch_fp8(const GemmArgs& g, int tiles_n, hipStream_t stream) {
-    switch (p256_pick_ni(g.M, tiles_n, p256_num_cus())) {
+    // The block-scaled path exists up to 192-row tiles (register budget, see the kernel).  Pick among those where the contraction is long
+    // enough for the matrix pipe to be what the tile waits for (tools/fp8_shapes.py, batch-256 forward shapes: K >= 1024 -7..-24 % against
+    // the non-scaled 224 / 256-row tiles, K <= 768 +5..+19 %: those products are bound by their epilogue and output stream, and the
+    // taller tile re-reads less).
+    const bool scaled = P256_FP8_SCALED != 0 && p256_k64() && g.K % 128 == 0 && g.K >= 1024;
+    int ni = g_p256_ni_forced();
+    if (ni == 0) ni = p256_pick_ni(g.M, tiles_n, p256_num_cus(), scaled ? P256_FP8_SCALED_MAX_NI : 8);
+    if (p256_k64() && g.K % 128 == 0 && g.K / 128 < 3 && ni < 6) ni = 6;      // two-step contraction: the two-stage ring (see p256_launch)
+    switch (ni) {
         case 4: p256_launch_fp8_ni<EPI, 4>(g, tiles_n, stream); break;
         case 5: p256_launch_fp8_ni<EPI, 5>(g, tiles_n, stream); break;
         case 6: p256_launch_fp8_ni<EPI, 6>(g, tiles_n, stream); break;
@@ -886,7 +956,6 @@ int mvuld_gemm_nt_p256_fp8(const GemmArgs& g, hipStream_t stream) {
     return 0;
 }
 
-static std::atomic<int> g_p256_ni{0};      // 0 = pick per shape; 4..8 = force (A/B timing)
 extern "C" int mvuld_set_gemm_p256_rows(int rows) {
     MV_CHECK_ARG(rows == 0 || (rows % 32 == 0 && rows >= 128 && rows <= 256), "set_gemm_p256_rows: 0 (auto) or 128, 160, 192, 224, 256");
     g_p256_ni.store(rows / 32, std::memory_order_relaxed);
@@ -895,10 +964,10 @@ extern "C" int mvuld_set_gemm_p256_rows(int rows) {
 
 // Tile height for an M x N product on a persistent grid of `cus` workgroups: the NI in 4..8 (rows = 32 * NI) that minimises
 // rounds(NI) x cost(NI), cost = a fixed share per tile (weights stage, prologue / epilogue latencies) + a share per 16-row fragment.
-static int p256_pick_ni(int M, int tiles_n, int cus) {
-    int best = 8;
+static int p256_pick_ni(int M, int tiles_n, int cus, int max_ni) {
+    int best = max_ni;
     double best_t = 1e30;
-    for (int ni = 8; ni >= 4; --ni) {
+    for (int ni = max_ni; ni >= 4; --ni) {
         const int64_t nt = cdiv(M, 32 * ni) * tiles_n;
         const double rounds = (double)cdiv(nt, cus);
         const double t = rounds * (0.28 + 0.09 * ni);

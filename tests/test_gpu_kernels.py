@@ -380,7 +380,8 @@ def test_quant_e4m3_matches_torch_float8(gpu, dtype):
 
 @pytest.mark.parametrize("M,N,K", [(6401, 2056, 576), (20000, 1288, 256), (769, 520, 1024), (25088, 768, 3072), (256, 8, 256)])
 def test_gemm_nt_fp8_vs_dequantised_product(gpu, M, N, K):
-    """The fp8 (OCP e4m3, v_mfma_f32_16x16x32_fp8_fp8) variant of the persistent 256 x 256 kernel: the product of the DEQUANTISED
+    """The fp8 (OCP e4m3; v_mfma_scale_f32_16x16x128_f8f6f4 on the K >= 1024 cases and on every 128-deep case whose tile the host picks
+    at <= 192 rows, v_mfma_f32_16x16x32_fp8_fp8 on the others) variant of the persistent 256 x 256 kernel: the product of the DEQUANTISED
     operands in fp32 is what the kernel must return (fp32 accumulation: only the bf16 rounding of the output separates them), with
     ragged M / N tails, bias, and the GELU epilogue with its pre-activation side output."""
     from mvuld_amd import ops, hip
