@@ -361,6 +361,11 @@ int mvuld_cross_entropy_soft(const float* logits, const float* target, const int
  * drawn on the host (numpy, as timm draws them). */
 int mvuld_mixup_batch(const void* x, void* y, const int64_t* target, float* soft_target, int B, int C, int H, int W, int K, float lam,
                       int cutmix, int yl, int yh, int xl, int xh, float smoothing, int dtype, mvuld_stream_t stream);
+/* The "elem" / "pair" modes of the same class (AUG.MIXUP_MODE, config.py:219): one parameter row per sample, params [B, 6] fp32 on the
+ * device = {lam, cutmix flag, yl, yh, xl, xh}; the partner of sample b is B-1-b as in batch mode ("pair": the host writes the same row
+ * for b and B-1-b).  Soft targets use each sample's own lam. */
+int mvuld_mixup_rows(const void* x, void* y, const int64_t* target, float* soft_target, int B, int C, int H, int W, int K,
+                     const float* params, float smoothing, int dtype, mvuld_stream_t stream);
 
 /* GATConv sparse part (dgl 0.8.1 u_add_v / edge_softmax / u_mul_e_sum; GraphModel.py:167-170) over CSR by destination */
 int mvuld_gat_scores_fwd(const void* ft, const float* al, const float* ar, float* el, float* er, int N, int H, int O,

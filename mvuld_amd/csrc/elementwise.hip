@@ -586,6 +586,52 @@ extern "C" int mvuld_mixup_batch(const void* x, void* y, const int64_t* target, 
     return 0;
 }
 
+// The same with one parameter row per sample (timm's "elem" and "pair" modes): params[b] = {lam, cutmix, yl, yh, xl, xh} as six floats.
+// The partner is still B-1-b; in "pair" mode the host writes the same row for b and B-1-b, in "elem" mode every sample has its own.
+template <typename T>
+__global__ __launch_bounds__(256) void mixup_rows_k(const T* __restrict__ x, T* __restrict__ y, int B, int64_t per, int H, int W,
+                                                    const float* __restrict__ params) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * per) return;
+    const int b = (int)(i / per);
+    const int64_t r = i - (int64_t)b * per;
+    const int64_t j = (int64_t)(B - 1 - b) * per + r;
+    const float* p = params + 6 * b;
+    const float lam = p[0];
+    if (p[1] != 0.f) {
+        const int w = (int)(r % W), h = (int)((r / W) % H);
+        y[i] = (h >= (int)p[2] && h < (int)p[3] && w >= (int)p[4] && w < (int)p[5]) ? x[j] : x[i];
+    } else if (lam == 1.0f) {
+        y[i] = x[i];
+    } else {
+        y[i] = (T)(lam * (float)x[i] + (1.0f - lam) * (float)x[j]);
+    }
+}
+__global__ void mixup_target_rows_k(const int64_t* __restrict__ target, float* __restrict__ out, int B, int K, const float* __restrict__ params,
+                                    float smoothing) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, k = i % K;
+    const float lam = params[6 * b];
+    const float off = smoothing / K, on = 1.0f - smoothing + off;
+    const float a = (int)target[b] == k ? on : off, c = (int)target[B - 1 - b] == k ? on : off;
+    out[i] = a * lam + c * (1.0f - lam);
+}
+extern "C" int mvuld_mixup_rows(const void* x, void* y, const int64_t* target, float* soft_target, int B, int C, int H, int W, int K,
+                                const float* params, float smoothing, int dtype, hipStream_t stream) {
+    MV_CHECK_ARG(x && y && x != y && params && B > 0 && C > 0 && H > 0 && W > 0, "mixup_rows: bad args (out of place)");
+    const int64_t per = (int64_t)C * H * W, total = (int64_t)B * per;
+    const unsigned grid = (unsigned)cdiv(total, 256);
+    if (dtype == MVULD_F32) hipLaunchKernelGGL(mixup_rows_k<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (float*)y, B, per, H, W, params);
+    else hipLaunchKernelGGL(mixup_rows_k<bf16>, dim3(grid), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, B, per, H, W, params);
+    if (target && soft_target) {
+        MV_CHECK_ARG(K > 0 && smoothing >= 0.f && smoothing < 1.f, "mixup_rows: classes / smoothing");
+        hipLaunchKernelGGL(mixup_target_rows_k, dim3((unsigned)cdiv((int64_t)B * K, 64)), dim3(64), 0, stream, target, soft_target, B, K, params, smoothing);
+    }
+    MV_LAUNCH_CHECK("mixup_rows");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ Swin continuous position bias table
 // table16[i,h] = 16*sigmoid( W2[h,:] . relu(W1 . coords[i] + b1) )   coords [T2,2], W1 [512,2], b1 [512], W2 [H,512]
 // (swin_transformer_v2.py:159-163).  hidden [T2,512] is kept for the backward.

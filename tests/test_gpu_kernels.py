@@ -193,7 +193,10 @@ K64_DEFAULT = int(os.environ.get("MVULD_P256_K64", "1"))      # keep in step wit
                                          (70000, 512, 128, 0), (70000, 512, 128, 160), (769, 520, 1024, 0),
                                          (6401, 2056, 576, 128), (6401, 2056, 576, 160), (6401, 2056, 576, 192), (6401, 2056, 576, 224),
                                          (6401, 2056, 576, 256), (20000, 1288, 192, 0), (25088, 512, 2048, 0), (16384, 2304, 768, 0),
-                                         (80001, 128, 512, 256), (80001, 128, 512, 0), (40000, 384, 128, 256), (33000, 192, 256, 224)])
+                                         (80001, 128, 512, 256), (80001, 128, 512, 0), (40000, 384, 128, 256), (33000, 192, 256, 224),
+                                         # two ring steps per tile on 160-row tiles, three column tiles: a three-stage ring would refill the bias slice of
+                                         # a tile two places ahead of its epilogue (round 4: such launches take the two-stage ring)
+                                         (70000, 768, 128, 160), (70000, 1288, 128, 128)])
 def test_gemm_p256_persistent_ragged(gpu, M, N, K, rows):
     """The persistent 256 x 256-tile kernel (csrc/gemm_p256.hip) forced on ragged shapes: M and N tails inside the last
     tiles, fewer tiles than CUs / several tiles per workgroup (the LDS-DMA ring and the bias slices run across tile

@@ -1219,6 +1219,54 @@ def test_mixup_cutmix_and_soft_target_cross_entropy(gpu):
     assert abs(float(loss) - float(ref)) < 1e-6 and rel(lg.grad, lr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["elem", "pair"])
+def test_mixup_elem_and_pair_modes(gpu, mode):
+    """AUG.MIXUP_MODE 'elem' / 'pair' (config.py:219; timm Mixup._mix_elem / _mix_pair): one (lam, box) per sample / per pair, partner
+    B-1-b, soft targets with each sample's own lam.  mvuld_mixup_rows against the per-sample torch loop of timm's formulas, driven by the
+    same parameter rows (the draws themselves: numpy calls in timm's order, checked here only for their structure -- pair rows
+    mirrored, lam corrected to the clipped box area, a share of samples left alone when prob < 1)."""
+    from mvuld_amd.data.mixup import Mixup
+    B, C, H, W, K = 8, 3, 20, 28, 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, H, W, generator=g)
+    y = torch.randint(0, K, (B,), generator=g)
+
+    def onehot(t, smoothing):
+        off = smoothing / K
+        return torch.full((B, K), off).scatter_(1, t.view(-1, 1), 1.0 - smoothing + off)
+    kinds = set()
+    for seed, (ma, ca, prob) in enumerate([(0.8, 1.0, 1.0), (0.8, 0.0, 1.0), (0.0, 1.0, 1.0), (0.8, 1.0, 0.5), (0.8, 1.0, 0.5), (0.8, 1.0, 1.0)]):
+        m = Mixup(mixup_alpha=ma, cutmix_alpha=ca, prob=prob, switch_prob=0.5, mode=mode, label_smoothing=0.1, num_classes=K)
+        np.random.seed(300 + seed)
+        rows = m.draw_rows(x.shape)
+        if mode == "pair":
+            assert np.array_equal(rows[:B // 2], rows[::-1][:B // 2])
+        for dtype in (torch.float32, torch.bfloat16):
+            xs = x.to(dtype)
+            np.random.seed(300 + seed)                  # the same draws again inside __call__
+            out, soft = m(xs.to(gpu), y.to(gpu))
+            ref = xs.clone()
+            for i in range(B):
+                lam, cut, yl, yh, xl, xh = (float(rows[i, 0]), rows[i, 1] != 0, *[int(v) for v in rows[i, 2:]])
+                j = B - 1 - i
+                if cut:
+                    ref[i][:, yl:yh, xl:xh] = xs[j][:, yl:yh, xl:xh]
+                    assert abs(lam - (1.0 - (yh - yl) * (xh - xl) / float(H * W))) < 1e-6
+                    kinds.add("cut")
+                elif lam != 1.0:
+                    ref[i] = (xs[i].float() * lam + xs[j].float() * (1.0 - lam)).to(dtype)
+                    kinds.add("mix")
+                else:
+                    kinds.add("none")
+            assert rel(out, ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+            cutrows = torch.from_numpy(rows[:, 1] != 0)
+            assert torch.equal(out.cpu()[cutrows], ref[cutrows])          # pasted boxes are copies: exact
+            lam_t = torch.from_numpy(rows[:, 0:1].copy())
+            tref = onehot(y, 0.1) * lam_t + onehot(y.flip(0), 0.1) * (1.0 - lam_t)
+            assert rel(soft, tref) < 1e-6
+    assert kinds == {"cut", "mix", "none"}
+
+
 def test_graphed_train_step_matches_eager(gpu):
     """The hipGraph-captured training step (graph_step.GraphedTrainStep: forward, CE, backward on the three streams, clip, fused AdamW
     with learning rate / bias corrections read from device memory, RNG step counter advanced inside the graph) against the same
