@@ -579,6 +579,41 @@ def test_head_gradients_vs_oracle(gpu, dtype):
     assert cos > (0.99999 if dtype == torch.float32 else 0.995)
 
 
+def test_rs_gcn_theta_phi_g_as_one_product(gpu):
+    """Rs_GCN with its parameters in a ParamStore (as every training run holds them): theta / phi / g run as ONE product over the
+    store-contiguous [3 Di, D] weight (models/Rs_GCN.py: _cat3) -- forward, the three weight / bias gradients, the input gradient --
+    against the three separate products of the same module (MVULD_RSGCN_CAT3 off).  Same fp32 split arithmetic per product; only the
+    input gradient's summation order differs (one K = 3 Di contraction instead of three chained ones)."""
+    from mvuld_amd.models import Rs_GCN as rs
+    from mvuld_amd.optimizer import ParamStore, split_decay
+    torch.manual_seed(3)
+    m = rs.Rs_GCN(512, 512).to(gpu).train()
+    with torch.no_grad():
+        m.W[1].weight.fill_(0.3)          # (zero-initialised in the reference: the block would be the identity)
+    store = ParamStore(list(split_decay(m)), gpu)
+    m._mv_store = store
+    assert rs._cat3(m, torch.float32) is not None, "theta / phi / g are not contiguous in the store"
+    B, N = 4, 96
+    v = torch.randn(B * N, 512, device=gpu)
+    go = torch.randn(B * N, 512, device=gpu)
+    res = []
+    for on in (True, False):
+        rs.CAT3[0] = on
+        try:
+            store.grad.zero_()
+            m.W[1].running_mean.zero_(); m.W[1].running_var.fill_(1.0)
+            x = v.clone().requires_grad_(True)
+            out, R = m.forward_rows(x, B)
+            out.backward(go)
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), R.clone(), x.grad.clone(), store.grad.clone()))
+        finally:
+            rs.CAT3[0] = True
+    for a, b, tol in zip(res[0], res[1], (1e-5, 1e-5, 2e-5, 2e-5)):
+        assert rel(a, b) < tol, rel(a, b)
+    assert float(res[0][3].abs().max()) > 0
+
+
 def test_rs_gcn_reference_layout(gpu):
     from mvuld_amd.models.Rs_GCN import Rs_GCN
     m = Rs_GCN(512, 512)
