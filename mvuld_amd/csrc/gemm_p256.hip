@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_p256(GemmArgs g, int tile
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (dyn && h == 0 && kt == 0 && wave == 0 && claim_fly) {      // the ticket has landed (lgkmcnt(0) above): publish tile ord + 1
                         unsigned ticket;
-                        asm volatile("s_mov_b32 %0, s101" : "=s"(ticket)::"s101");
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, s101" : "=s"(ticket)::"s101", "memory");      // (the wait is in the statement: nothing can come between)
                         const int pn = (bx & 7) + dyn_base + 8 * (int)ticket;
                         asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(claim_a + ((ord + 1) & 1) * 4), "v"(pn < nt ? pn : -1) : "memory");
                         claim_fly = false;
