@@ -490,6 +490,8 @@ def make_roofline(fam, ms_per_step):
     if len(ranked) > 1:
         r["runner_up"] = roofline_of(ranked[1][0], ranked[1][1], ms_per_step)
     r["top_kernels_ms"] = [(k, round(v["ms"], 3), v["n"]) for k, v in ranked[:8]]
+    from mvuld_amd import hip
+    r["event_bracket_us_subtracted"] = round(hip.TIMING.bracket_us or 0.0, 2)      # per launch: what the event pair itself costs (hip.py: calibrate)
     return r
 
 
