@@ -365,6 +365,8 @@ def main(argv=None):
     torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
     from mvuld_amd import ops as _ops
     _ops.seed_rng(seed, rank)                          # dropout / DropPath mask streams: per seed AND per rank
+    if use_cuda:
+        _ops.use_priority_main_stream(device)          # the step's critical chain (image encoder) ahead of the side streams' queues
     ws = world_size()
     # linear LR scaling with the global batch (:545-558)
     scale = config.DATA.BATCH_SIZE * ws / 512.0

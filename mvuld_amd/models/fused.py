@@ -13,6 +13,10 @@ from .swin_transformer_v2 import SwinTransformerV2
 from .unixcoder import MyUniXcoder, RobertaConfigLite, RobertaModel
 
 
+# Stream priorities of the side streams (experiment knob MVULD_STREAM_PRIO="text,wgrad,graph", e.g. "1,1,1" = all below the image encoder's
+# stream; HIP: larger number = lower priority, clamped to the device's range).  Default: all equal.
+_PRIO = dict(zip(("text", "wgrad", "graph"), (int(v) for v in os.environ.get("MVULD_STREAM_PRIO", "0,0,0").split(","))))
+
 class FusedMVulD(nn.Module):
     def __init__(self, config, roberta_config=None, act_dtype=torch.bfloat16, swin=None):
         super().__init__()
@@ -104,10 +108,10 @@ class FusedMVulD(nn.Module):
                 while len(self._inflight) > self.max_steps_in_flight:
                     self._inflight.pop(0).synchronize()
             if self._side is None:
-                self._side = torch.cuda.Stream(device=images.device)
+                self._side = torch.cuda.Stream(device=images.device, priority=_PRIO["text"])
             side = self._side
             if self._wg is None:
-                self._wg = torch.cuda.Stream(device=images.device)
+                self._wg = torch.cuda.Stream(device=images.device, priority=_PRIO["wgrad"])
             ops.register_grad_stream(side)
             ops.register_grad_stream(self._wg)
             # third stream: the image encoder's weight gradients (nothing in backward depends on them); joined into the main
@@ -118,7 +122,7 @@ class FusedMVulD(nn.Module):
             gst = side
             if self._split_head and os.environ.get("MVULD_GRAPH_STREAM", "1") != "0":
                 if self._gs is None:
-                    self._gs = torch.cuda.Stream(device=images.device)
+                    self._gs = torch.cuda.Stream(device=images.device, priority=_PRIO["graph"])
                 gst = self._gs
                 ops.register_grad_stream(gst)
                 gst.wait_stream(main)                                  # inputs are ready; nothing of this step is on `main` yet

@@ -58,6 +58,21 @@ def fire_backward_done(tag):
         WGRAD_STREAM[0] = None            # the step's backward is over: later launches (other models, tests) stay on their own stream
 
 
+def use_priority_main_stream(device=None):
+    """Make the calling thread's current stream a HIGH-priority one (the training drivers call this once, after set_device).  The fused
+    step's critical chain is the image encoder on the current stream; the text encoder, the graph branch and the weight gradients run on
+    side streams created by the model at default priority.  With the chain's queue served first the step is 0.2-0.6 ms shorter (40-step
+    A/B/A/B on two boxes: 51.56 / 51.53 -> 50.91 / 50.94 ms and 50.85 / 51.01 -> 50.63 / 50.38 ms; every side stream high and the chain low:
+    +0.3 ms).  gfx950 has two levels (torch.cuda.Stream.priority_range() = (0, -1)).  MVULD_MAIN_PRIO=0 keeps the default stream."""
+    prio = int(os.environ.get("MVULD_MAIN_PRIO", "-1"))
+    if prio == 0 or not torch.cuda.is_available():
+        return None
+    s = torch.cuda.Stream(device=device, priority=prio)
+    s.wait_stream(torch.cuda.current_stream(device))
+    torch.cuda.set_stream(s)
+    return s
+
+
 def begin_step():
     """Called where a training step starts (FusedMVulD.forward): drops whatever a backward that raised left deferred -- LayerNorm
     parameter-gradient partials, an open weight-gradient group -- so that it cannot reach this step's gradients, and
