@@ -109,7 +109,9 @@ def main():
     device = torch.device(f"cuda:{local}")
     from mvuld_amd import hip, ops
     hip.LIB.load()
-    ops.use_priority_main_stream()             # as main_bigvul.py does: the step's critical chain on a high-priority stream
+    if args.mode == "train" and not args.graph:
+        ops.use_priority_main_stream()         # as main_bigvul.py does: the EAGER step's critical chain on a high-priority stream;
+                                               # captured graphs run slower beside a priority stream, so the graph modes stay on the default one
     from mvuld_amd.distributed import attach_gradient_exchange, broadcast_parameters, init_distributed, world_size
     import torch.distributed as dist
     if world > 1:
